@@ -1,0 +1,161 @@
+/*
+ * lidarcrafter_hip.h -- C ABI of the MI355X (gfx950) hot path of LiDARCrafter's range-image
+ * diffusion denoiser.  Built as lidarcrafter_amd/liblidarcrafter_hip.so by hipcc.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", return int: 0 = ok, >0 = hipError_t of the launch, <0 = LC_E* argument error.
+ *   - raw DEVICE pointers + sizes + a hipStream_t passed as void* (NULL = default stream).
+ *   - no allocation, no synchronisation, no host<->device copies inside: every call is legal
+ *     under hipStreamBeginCapture (HIP graphs).
+ *   - tensors are fp32, [B, C, H, W] with the inner [C, H, W] block contiguous; `*_bs` is the
+ *     batch stride in ELEMENTS (>= C*H*W).  A channel slice of a wider buffer is therefore a
+ *     valid tensor, which is how torch.cat([h, skip], 1) of the reference
+ *     (efficient_unet.py:293-295, layout_unet_v1.py:893) is made free: producers write into
+ *     slices of one pre-concatenated buffer.
+ *
+ * Each function cites the reference code it replaces (paths relative to /root/reference/).
+ * The reference reaches these through ATen ops of its nn.Modules, not through an FFI of its
+ * own; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ */
+#ifndef LIDARCRAFTER_HIP_H
+#define LIDARCRAFTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_OK 0
+#define LC_EINVAL (-1)  /* bad size / null pointer */
+#define LC_EUNSUP (-2)  /* shape outside what the kernels are instantiated for */
+
+typedef void* lc_stream_t;
+
+/* Library / device probe.  Returns the ABI version (this header = 1). */
+int lc_abi_version(void);
+/* Writes gcnArchName of the current device into buf (NUL terminated). */
+int lc_device_arch(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution: lidargen/models/unets/ops.py:149-173 (ops.Conv2d) with ops.py:32-49 (Pad,
+ * ring=True: W circular, H zeros) for 3x3, and plain 1x1 (ring=False, padding 0).
+ * Used by every conv of EfficientUNet (efficient_unet.py:79,89,94,141,179,260,271) and
+ * LayoutUnetV1 (nn.py:34-44 conv_nd_range; Conv1d 1x1 projections layout_unet_v1.py:386-399).
+ *
+ * Weights are consumed in a PACKED layout wp[tap][Cip][Cop] (tap = ky*ks+kx, Cip = Ci rounded
+ * up to 8, Cop = Co rounded up to 64, zero filled) produced once per weight version by
+ * lc_pack_conv_weight from the checkpoint layout OIHW [Co][Ci][ks][ks].
+ * Arithmetic: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32) accumulate == an fmaf chain.
+ *   y = (conv(x) + bias [+ res]) * out_scale          (ResidualBlock efficient_unet.py:111-115)
+ * ------------------------------------------------------------------------------------------- */
+int64_t lc_packed_conv_weight_elems(int Co, int Ci, int ks);
+int lc_pack_conv_weight(const float* w_oihw, float* wp, int Co, int Ci, int ks, lc_stream_t s);
+int lc_conv2d_ring_fwd(const float* x, int64_t x_bs, const float* wp, const float* bias,
+                       const float* res, int64_t res_bs, float* y, int64_t y_bs,
+                       int B, int Ci, int Co, int H, int W, int ks, float out_scale,
+                       int tile_cfg /* 0 = auto */, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ affine | + AdaGN scale/shift) (+ SiLU):
+ *   nn.GroupNorm(8, C, 1e-6) efficient_unet.py:37,77; ops.AdaGN ops.py:176-200;
+ *   GroupNorm32 nn.py:17-19 + scale-shift norm layout_unet_v1.py:243-245; nn.SiLU.
+ * Two launches: lc_groupnorm_stats writes per-(b,g,chunk) fp64 partial (sum, sumsq) into
+ * `partials` (>= lc_groupnorm_partials_elems doubles); lc_groupnorm_apply folds them in a fixed
+ * order (deterministic), then
+ *   y = ((x-mean)*rstd * gamma[c] + beta[c]) * (1 + scale[b,c]) + shift[b,c] ; y = silu(y) if act
+ * gamma/beta may be NULL (affine=False); scale/shift may be NULL; ss_bs = batch stride of
+ * scale/shift rows in elements.
+ * ------------------------------------------------------------------------------------------- */
+int64_t lc_groupnorm_partials_elems(int B, int C, int H, int W, int G);
+int lc_groupnorm_stats(const float* x, int64_t x_bs, double* partials, int B, int C, int H, int W,
+                       int G, lc_stream_t s);
+int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials, const float* gamma,
+                       const float* beta, const float* scale, const float* shift, int64_t ss_bs,
+                       float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
+                       int act_silu, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * FIR resampling x2, window [1,3,3,1], ring=True: ops.Resample ops.py:52-146
+ * (closed forms SURVEY.md §8a-10).  dir = +1 upsample (H,W -> 2H,2W), -1 downsample.
+ * ------------------------------------------------------------------------------------------- */
+int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H,
+                      int W, int dir, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small dense layer  y[m, n] = sum_k act(x[m,k]) * w[n,k] + b[n]   (w in nn.Linear layout).
+ * Time-embedding MLP efficient_unet.py:237-242 / layout_unet_v1.py:683-688, AdaGN projection
+ * ops.py:190-194, ResBlock.emb_layers layout_unet_v1.py:196-202.  act_in: 0 none, 1 SiLU.
+ * lc_sinusoid: ops.SinusoidalPositionalEmbedding ops.py:14-29 (input = log-SNR).
+ * ------------------------------------------------------------------------------------------- */
+int lc_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
+                  int act_in, int act_out, lc_stream_t s);
+int lc_sinusoid_fwd(const float* t, float* y, int M, int channels, float max_period,
+                    lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention over range-image tokens, channel-major operands (a [d, L] matrix per head with L
+ * contiguous), flash-style (no score matrix in HBM), fp32 MFMA for QK^T and PV:
+ *   o[c, t] = sum_s softmax_s(scale * sum_c' q[c',t] k[c',s]) v[c, s]
+ * nn.MultiheadAttention in SelfAttentionBlock efficient_unet.py:28-58;
+ * QKVAttentionLegacy layout_unet_v1.py:555-596; ObjectAwareCrossAttention.forward
+ * layout_unet_v1.py:489-506 (image keys ++ 13 layout keys, d_qk = 2*d_v).
+ * Head (b,h) of operand X starts at X + b*X_bs + h*X_hs; channel stride X_cs.
+ * Keys/values may come in two segments (k/v: Lk0 tokens, k2/v2: Lk1 tokens; pass NULL,0).
+ * ------------------------------------------------------------------------------------------- */
+int lc_attention_fwd(const float* q, int64_t q_bs, int64_t q_hs, int64_t q_cs,
+                     const float* k, int64_t k_bs, int64_t k_hs, int64_t k_cs,
+                     const float* v, int64_t v_bs, int64_t v_hs, int64_t v_cs,
+                     const float* k2, int64_t k2_bs, int64_t k2_hs, int64_t k2_cs,
+                     const float* v2, int64_t v2_bs, int64_t v2_hs, int64_t v2_cs,
+                     float* o, int64_t o_bs, int64_t o_hs, int64_t o_cs,
+                     int B, int heads, int Lq, int Lk0, int Lk1, int dqk, int dv, float scale,
+                     lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reverse-diffusion update, one fused elementwise pass:
+ *   ContinuousTimeGaussianDiffusion.p_step continuous_time.py:209-231 (also
+ *   continuous_time_cond.py:229-252).  coef[b*8 + ...] = {alpha_t, sigma_t, alpha_s, sigma_s,
+ *   k0, k1, clip_range (<=0: no clip), unused}: ddpm k0 = c = -expm1(l_t-l_s), k1 = sigma_s*sqrt(c);
+ *   ddim k0 = c1, k1 = c2.  objective: 0 eps, 1 v, 2 x_0.  mode: 0 ddpm, 1 ddim.
+ *   noise may be NULL when its coefficient is 0 (ddim eta=0).  n = C*H*W per sample.
+ * ------------------------------------------------------------------------------------------- */
+int lc_pstep_fwd(const float* x_t, int64_t xt_bs, const float* pred, int64_t pred_bs,
+                 const float* noise, int64_t noise_bs, const float* coef, float* x_s,
+                 int64_t xs_bs, int B, int64_t n, int objective, int mode, lc_stream_t s);
+
+/* Strided copy of [B, C*H*W] blocks (fills a channel slice of a concat buffer). */
+int lc_copy_strided(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int64_t n,
+                    lc_stream_t s);
+/* y = (a + b) * scale  (SelfAttentionBlock residual efficient_unet.py:55-57). */
+int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_t b_bs, float* y,
+                 int64_t y_bs, int B, int64_t n, float scale, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Point cloud -> range image, lidargen/dataset/transforms_3d/common.py:26-91 with
+ * scan_unfolding=False: spherical cell per point, nearest point per cell wins (z-buffer via
+ * 64-bit atomicMin on (depth_bits<<32 | point_idx); equal depths: lowest index wins), mask
+ * channel = depth in [min_depth, max_depth] applied by the caller like the reference.
+ * points [N,4] (x,y,z,intensity); zbuf u64[H*W] scratch; image [H,W,6]; winner int32[H*W] (-1
+ * empty) may be NULL; cells int32[N,2] (grid_h, grid_w) may be NULL.  All float32 operations
+ * correctly rounded (asin/atan2 evaluated in fp64, rounded once) -- see oracle/lidar.py "f32".
+ * ------------------------------------------------------------------------------------------- */
+int lc_project_points(const float* points, int N, int H, int W, float fov_up_deg,
+                      float fov_down_deg, float min_depth, float max_depth, uint64_t* zbuf,
+                      float* image, int32_t* winner, int32_t* cells, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Points in rotated boxes: lidargen/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:128-168
+ * (points_in_boxes_cpu: int32 [N_box, M] 0/1, MARGIN 1e-2) and
+ * src/roiaware_pool3d_kernel.cu:23-36,313-336 (points_in_boxes_gpu: int32 [B, M] index of the
+ * first containing box or -1, MARGIN 1e-5).  boxes [.., 7] = x,y,z,dx,dy,dz,heading.
+ * ------------------------------------------------------------------------------------------- */
+int lc_points_in_boxes_mask(const float* boxes, int n_boxes, const float* pts, int n_pts,
+                            float margin, int32_t* out_mask, lc_stream_t s);
+int lc_points_in_boxes_index(const float* boxes, const float* pts, int B, int n_boxes, int n_pts,
+                             float margin, int32_t* out_idx, lc_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARCRAFTER_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of include/lidarcrafter_hip.h.  There is NO fallback: if the shared library is
+missing the import of any compute op raises, so a GPU box can never silently run a CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB
+
+i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/lidarcrafter_hip.h one to one
+SIGNATURES = {
+    "lc_abi_version": (i32, []),
+    "lc_device_arch": (i32, [C.c_char_p, i32]),
+    "lc_packed_conv_weight_elems": (i64, [i32, i32, i32]),
+    "lc_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, vp]),
+    "lc_conv2d_ring_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32,
+                                 f32, i32, vp]),
+    "lc_groupnorm_partials_elems": (i64, [i32, i32, i32, i32, i32]),
+    "lc_groupnorm_stats": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
+    "lc_groupnorm_apply": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
+                                 i32, f32, i32, vp]),
+    "lc_resample2x_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "lc_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "lc_sinusoid_fwd": (i32, [vp, vp, i32, i32, f32, vp]),
+    "lc_attention_fwd": (i32, [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64,
+                               vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64,
+                               i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
+    "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),
+    "lc_add_scale": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, f32, vp]),
+    "lc_project_points": (i32, [vp, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
+    "lc_points_in_boxes_mask": (i32, [vp, i32, vp, i32, f32, vp, vp]),
+    "lc_points_in_boxes_index": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise HipLibraryMissing(
+                f"{LIB} not found: run `python -m lidarcrafter_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the hot path.")
+        handle = C.CDLL(LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.lc_abi_version() != 1:
+            raise HipLibraryMissing("ABI version mismatch, rebuild the library")
+        _lib = handle
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape"}.get(code, f"hipError {code}")
+        raise HipError(f"{what}: {kind}")

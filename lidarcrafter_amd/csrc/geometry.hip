@@ -1,0 +1,150 @@
+// Point-cloud side of the path: spherical projection z-buffer and points-in-boxes.
+// HBM-bound gather/scatter work: coalesced point reads, 64-bit atomics for the z-buffer.
+#include "common.h"
+
+namespace {
+
+#pragma clang fp contract(off)
+
+// lidargen/dataset/transforms_3d/common.py:44-45,72-81 -- every float32 op correctly rounded
+// (asin/atan2 in fp64, rounded once), matching oracle/lidar.py project_cells(mode="f32").
+__device__ __forceinline__ void cell_of(float x, float y, float z, int H, int W, float h_up,
+                                        float h_down, float& depth, int& gh, int& gw) {
+    depth = sqrtf((x * x + y * y) + z * z);
+    const float t = z / (depth + 1e-6f);
+    const float elev = (float)asin((double)t) + fabsf(h_down);
+    float fh = 1.0f - elev / (h_up - h_down);
+    fh = floorf(fh * (float)H);
+    gh = (int)fminf(fmaxf(fh, 0.f), (float)(H - 1));
+    const float az = -(float)atan2((double)y, (double)x);
+    float fw = (az / 3.14159274101257324f + 1.0f) / 2.0f;
+    fw = fw - floorf(fw);              // np.mod(v, 1) for v in [0, 1]
+    fw = floorf(fw * (float)W);
+    gw = (int)fminf(fmaxf(fw, 0.f), (float)(W - 1));
+}
+
+__global__ void zbuf_clear_kernel(unsigned long long* zb, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) zb[i] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void project_scatter_kernel(const float* __restrict__ pts, int N,
+                                                             int H, int W, float h_up,
+                                                             float h_down,
+                                                             unsigned long long* __restrict__ zb,
+                                                             int* __restrict__ cells) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pts + 4ll * i);
+    float depth; int gh, gw;
+    cell_of(p.x, p.y, p.z, H, W, h_up, h_down, depth, gh, gw);
+    if (cells) { cells[2 * i] = gh; cells[2 * i + 1] = gw; }
+    if (depth != depth) return;  // NaN never wins (numpy argsort puts NaN last -> overwritten)
+    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)i;
+    atomicMin(zb + (long long)gh * W + gw, key);
+}
+
+__global__ __launch_bounds__(256) void project_gather_kernel(const float* __restrict__ pts, int HW,
+                                                            const unsigned long long* __restrict__ zb,
+                                                            float min_d, float max_d,
+                                                            float* __restrict__ img,
+                                                            int* __restrict__ winner) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= HW) return;
+    const unsigned long long key = zb[c];
+    float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int win = -1;
+    if (key != ~0ull) {
+        win = (int)(key & 0xFFFFFFFFull);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pts + 4ll * win);
+        const float depth = __uint_as_float((unsigned)(key >> 32));
+        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = p.w; o[4] = depth;
+        o[5] = (depth >= min_d && depth <= max_d) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) img[6ll * c + k] = o[k];
+    if (winner) winner[c] = win;
+}
+
+// roiaware_pool3d.cpp:121-140 / roiaware_pool3d_kernel.cu:16-36: float rotation, double compares.
+__device__ __forceinline__ int pt_in_box(float x, float y, float z, const float* bx, float margin) {
+    const float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5], rz = bx[6];
+    if ((double)fabsf(z - cz) > (double)dz / 2.0) return 0;
+    const float cosa = (float)cos((double)(-rz)), sina = (float)sin((double)(-rz));
+    const float sx = x - cx, sy = y - cy;
+    const float lx = sx * cosa + sy * (-sina);
+    const float ly = sx * sina + sy * cosa;
+    return ((double)fabsf(lx) < (double)dx / 2.0 + (double)margin) &
+           ((double)fabsf(ly) < (double)dy / 2.0 + (double)margin);
+}
+
+__global__ __launch_bounds__(256) void pib_mask_kernel(const float* __restrict__ boxes, int nb,
+                                                      const float* __restrict__ pts, int np,
+                                                      float margin, int* __restrict__ out) {
+    extern __shared__ float sb[];
+    for (int i = threadIdx.x; i < nb * 7; i += 256) sb[i] = boxes[i];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= np) return;
+    const float x = pts[3ll * j], y = pts[3ll * j + 1], z = pts[3ll * j + 2];
+    for (int k = 0; k < nb; ++k) out[(long long)k * np + j] = pt_in_box(x, y, z, sb + 7 * k, margin);
+}
+
+__global__ __launch_bounds__(256) void pib_index_kernel(const float* __restrict__ boxes, int nb,
+                                                       const float* __restrict__ pts, int np,
+                                                       float margin, int* __restrict__ out) {
+    extern __shared__ float sb[];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < nb * 7; i += 256) sb[i] = boxes[(long long)b * nb * 7 + i];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= np) return;
+    const float* p = pts + ((long long)b * np + j) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    int idx = -1;
+    for (int k = 0; k < nb; ++k)
+        if (pt_in_box(x, y, z, sb + 7 * k, margin)) { idx = k; break; }
+    out[(long long)b * np + j] = idx;
+}
+
+}  // namespace
+
+extern "C" int lc_project_points(const float* points, int N, int H, int W, float fov_up_deg,
+                                 float fov_down_deg, float min_depth, float max_depth,
+                                 uint64_t* zbuf, float* image, int32_t* winner, int32_t* cells,
+                                 lc_stream_t s) {
+    if (!points || !zbuf || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(points) & 15) return LC_EINVAL;
+    const int HW = H * W;
+    // np.deg2rad in float64 then rounded to float32 (oracle/lidar.py mode="f32")
+    const float h_up = (float)((double)fov_up_deg * 0.017453292519943295);
+    const float h_down = (float)((double)fov_down_deg * 0.017453292519943295);
+    auto zb = reinterpret_cast<unsigned long long*>(zbuf);
+    hipLaunchKernelGGL(zbuf_clear_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), zb, HW);
+    if (N > 0)
+        hipLaunchKernelGGL(project_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, lc_s(s),
+                           points, N, H, W, h_up, h_down, zb, cells);
+    hipLaunchKernelGGL(project_gather_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
+                       HW, zb, min_depth, max_depth, image, winner);
+    return lc_launch_status();
+}
+
+extern "C" int lc_points_in_boxes_mask(const float* boxes, int n_boxes, const float* pts, int n_pts,
+                                       float margin, int32_t* out_mask, lc_stream_t s) {
+    if (!boxes || !pts || !out_mask || n_boxes <= 0 || n_pts <= 0) return LC_EINVAL;
+    if (n_boxes * 7 * sizeof(float) > 60000) return LC_EUNSUP;
+    hipLaunchKernelGGL(pib_mask_kernel, dim3((n_pts + 255) / 256), dim3(256),
+                       n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
+                       out_mask);
+    return lc_launch_status();
+}
+
+extern "C" int lc_points_in_boxes_index(const float* boxes, const float* pts, int B, int n_boxes,
+                                        int n_pts, float margin, int32_t* out_idx, lc_stream_t s) {
+    if (!boxes || !pts || !out_idx || B <= 0 || n_boxes <= 0 || n_pts <= 0) return LC_EINVAL;
+    if (n_boxes * 7 * sizeof(float) > 60000) return LC_EUNSUP;
+    hipLaunchKernelGGL(pib_index_kernel, dim3((n_pts + 255) / 256, B), dim3(256),
+                       n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
+                       out_idx);
+    return lc_launch_status();
+}

@@ -1,0 +1,184 @@
+// Small kernels around the denoiser: dense layers of the time/AdaGN MLPs, sinusoid embedding,
+// the fused reverse-diffusion update, strided copy and residual add.  All HBM/latency bound.
+#include "common.h"
+
+namespace {
+
+// y[m,n] = act_out( sum_k act_in(x[m,k]) w[n,k] + b[n] ); one wave per output column n, lanes
+// split K (coalesced rows of w), all M rows of x handled by the same wave so w is read once.
+template <int MT>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x,
+                                                    const float* __restrict__ w,
+                                                    const float* __restrict__ b,
+                                                    float* __restrict__ y, int M, int K, int N,
+                                                    int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m0 = blockIdx.y * MT;
+    if (n >= N) return;
+    float acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = 0.f;
+    const float* wr = w + (long long)n * K;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            if (m0 + i < M) {
+                float xv = x[(long long)(m0 + i) * K + k];
+                if (act_in) xv = lc_silu(xv);
+                acc[i] = fmaf(xv, wv, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float v = lc_wave_sum(acc[i]);
+        if (lane == 0 && m0 + i < M) {
+            if (b) v += b[n];
+            if (act_out) v = lc_silu(v);
+            y[(long long)(m0 + i) * N + n] = v;
+        }
+    }
+}
+
+__global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ y, int M,
+                                int channels, float max_period) {
+    const int half = channels / 2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * half) return;
+    const int m = e / half, k = e - m * half;
+    // ops.py:22-25: h = exp(-ln(max_period)/(half-1) * k); arg = t*h; cat[sin, cos]
+    const float h = expf((-logf(max_period) / (float)(half - 1)) * (float)k);
+    const float a = t[m] * h;
+    y[(long long)m * channels + k] = sinf(a);
+    y[(long long)m * channels + half + k] = cosf(a);
+}
+
+#pragma clang fp contract(off)
+// continuous_time.py:209-231; same op order as the reference so fp32 rounding agrees.
+__global__ __launch_bounds__(256) void pstep_kernel(
+    const float* __restrict__ x_t, long long xt_bs, const float* __restrict__ pred,
+    long long pred_bs, const float* __restrict__ noise, long long noise_bs,
+    const float* __restrict__ coef, float* __restrict__ x_s, long long xs_bs, long long n,
+    int objective, int mode) {
+    const int b = blockIdx.y;
+    const float* cf = coef + b * 8;
+    const float a_t = cf[0], s_t = cf[1], a_s = cf[2], s_s = cf[3], k0 = cf[4], k1 = cf[5];
+    const float clip = cf[6];
+    (void)s_s;
+    const float* xp = x_t + b * xt_bs;
+    const float* pp = pred + b * pred_bs;
+    const float* np_ = noise ? noise + b * noise_bs : nullptr;
+    float* op = x_s + b * xs_bs;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float xt = xp[i], pr = pp[i];
+        float x0;
+        if (objective == 0) x0 = (xt - s_t * pr) / a_t;
+        else if (objective == 1) x0 = a_t * xt - s_t * pr;
+        else x0 = pr;
+        if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+        const float nz = np_ ? np_[i] : 0.f;
+        float out;
+        if (mode == 0) {  // ddpm: k0 = c, k1 = sigma_s*sqrt(c)
+            const float mean = a_s * (xt * (1.f - k0) / a_t + k0 * x0);
+            out = mean + k1 * nz;
+        } else {          // ddim: k0 = c1, k1 = c2
+            const float eps = (xt - a_t * x0) / s_t;
+            out = a_s * x0 + k0 * nz + k1 * eps;
+        }
+        op[i] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ x, long long x_bs,
+                                                  float* __restrict__ y, long long y_bs,
+                                                  long long n) {
+    const int b = blockIdx.y;
+    const float* xp = x + b * x_bs;
+    float* yp = y + b * y_bs;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        yp[i] = xp[i];
+}
+
+__global__ __launch_bounds__(256) void add_scale_kernel(const float* __restrict__ a, long long a_bs,
+                                                       const float* __restrict__ bb, long long b_bs,
+                                                       float* __restrict__ y, long long y_bs,
+                                                       long long n, float scale) {
+    const int b = blockIdx.y;
+    const float* ap = a + b * a_bs;
+    const float* bp = bb + b * b_bs;
+    float* yp = y + b * y_bs;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        yp[i] = (ap[i] + bp[i]) * scale;
+}
+
+inline int grid_for(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int lc_abi_version(void) { return 1; }
+
+extern "C" int lc_device_arch(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return LC_EINVAL;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return (int)e;
+    int i = 0;
+    for (; i < buflen - 1 && p.gcnArchName[i]; ++i) buf[i] = p.gcnArchName[i];
+    buf[i] = 0;
+    return LC_OK;
+}
+
+extern "C" int lc_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K,
+                             int N, int act_in, int act_out, lc_stream_t s) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return LC_EINVAL;
+    constexpr int MT = 8;
+    dim3 grid((N + 3) / 4, (M + MT - 1) / MT);
+    hipLaunchKernelGGL(linear_kernel<MT>, grid, dim3(256), 0, lc_s(s), x, w, b, y, M, K, N, act_in,
+                       act_out);
+    return lc_launch_status();
+}
+
+extern "C" int lc_sinusoid_fwd(const float* t, float* y, int M, int channels, float max_period,
+                               lc_stream_t s) {
+    if (!t || !y || M <= 0 || channels < 4 || (channels & 1)) return LC_EINVAL;
+    const int n = M * (channels / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, lc_s(s), t, y, M,
+                       channels, max_period);
+    return lc_launch_status();
+}
+
+extern "C" int lc_pstep_fwd(const float* x_t, int64_t xt_bs, const float* pred, int64_t pred_bs,
+                            const float* noise, int64_t noise_bs, const float* coef, float* x_s,
+                            int64_t xs_bs, int B, int64_t n, int objective, int mode,
+                            lc_stream_t s) {
+    if (!x_t || !pred || !coef || !x_s || B <= 0 || n <= 0) return LC_EINVAL;
+    if (objective < 0 || objective > 2 || mode < 0 || mode > 1) return LC_EINVAL;
+    hipLaunchKernelGGL(pstep_kernel, dim3(grid_for(n), B), dim3(256), 0, lc_s(s), x_t,
+                       (long long)xt_bs, pred, (long long)pred_bs, noise, (long long)noise_bs, coef,
+                       x_s, (long long)xs_bs, (long long)n, objective, mode);
+    return lc_launch_status();
+}
+
+extern "C" int lc_copy_strided(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B,
+                               int64_t n, lc_stream_t s) {
+    if (!x || !y || B <= 0 || n <= 0) return LC_EINVAL;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for(n), B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
+                       y, (long long)y_bs, (long long)n);
+    return lc_launch_status();
+}
+
+extern "C" int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_t b_bs, float* y,
+                            int64_t y_bs, int B, int64_t n, float scale, lc_stream_t s) {
+    if (!a || !b || !y || B <= 0 || n <= 0) return LC_EINVAL;
+    hipLaunchKernelGGL(add_scale_kernel, dim3(grid_for(n), B), dim3(256), 0, lc_s(s), a,
+                       (long long)a_bs, b, (long long)b_bs, y, (long long)y_bs, (long long)n, scale);
+    return lc_launch_status();
+}

@@ -1,0 +1,123 @@
+// GroupNorm statistics + fused normalise / affine / AdaGN scale-shift / SiLU.
+// Reference: nn.GroupNorm(8,C,1e-6) efficient_unet.py:37,77; ops.AdaGN ops.py:176-200;
+// GroupNorm32 + scale-shift layout_unet_v1.py:243-245 / nn.py:17-19.  HBM-bound: stats reads the
+// tensor once (float4, fp32 lane partials over <=64 values, fp64 wave/block reduction),
+// apply reads once and writes once.  A group is a contiguous span of (C/G)*H*W floats in NCHW.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_CHUNK = 16384;  // elements per stats block (64 KiB)
+
+__host__ __device__ inline int gn_chunks(long long n) { return (int)((n + GN_CHUNK - 1) / GN_CHUNK); }
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long long x_bs,
+                                                      double* __restrict__ part, int C, int G,
+                                                      long long HW, int nch) {
+    const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int cpg = C / G;
+    const long long n = (long long)cpg * HW;
+    const float* p = x + b * x_bs + (long long)g * n;
+    const long long lo = (long long)chunk * GN_CHUNK;
+    const long long hi = (lo + GN_CHUNK < n) ? lo + GN_CHUNK : n;
+    float s = 0.f, q = 0.f;
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+        for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = p[i];
+            s += v; q += v * v;
+        }
+    }
+    double ds = lc_wave_sum((double)s), dq = lc_wave_sum((double)q);
+    __shared__ double sh[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w] = ds; sh[4 + w] = dq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* o = part + (((long long)b * G + g) * nch + chunk) * 2;
+        o[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        o[1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    }
+}
+
+// one block per (b, c, slab of the H*W plane)
+__global__ __launch_bounds__(256) void gn_apply_kernel(
+    const float* __restrict__ x, long long x_bs, const double* __restrict__ part,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+    const float* __restrict__ shift, long long ss_bs, float* __restrict__ y, long long y_bs, int C,
+    int G, long long HW, int nch, float eps, int act) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int cpg = C / G, g = c / cpg;
+    const double* pp = part + ((long long)b * G + g) * nch * 2;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nch; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
+    const double n = (double)cpg * (double)HW;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)mean;
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+    const float sh = shift ? shift[b * ss_bs + c] : 0.0f;
+    const float* xp = x + b * x_bs + (long long)c * HW;
+    float* yp = y + b * y_bs + (long long)c * HW;
+    const long long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per;
+    const long long hi = lo + per < HW ? lo + per : HW;
+    auto f = [&](float v) {
+        float t = (v - mu) * rstd;
+        t = t * ga + be;
+        t = t * sc + sh;
+        return act ? lc_silu(t) : t;
+    };
+    const bool vec = (HW & 3) == 0 && (per & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0;
+    if (vec) {
+        for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
+            v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+            *reinterpret_cast<f32x4*>(yp + i) = v;
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) yp[i] = f(xp[i]);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t lc_groupnorm_partials_elems(int B, int C, int H, int W, int G) {
+    if (G <= 0 || C % G) return 0;
+    return (int64_t)B * G * gn_chunks((long long)(C / G) * H * W) * 2;
+}
+
+extern "C" int lc_groupnorm_stats(const float* x, int64_t x_bs, double* partials, int B, int C,
+                                  int H, int W, int G, lc_stream_t s) {
+    if (!x || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
+    const long long HW = (long long)H * W;
+    const int nch = gn_chunks((long long)(C / G) * HW);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, G, B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
+                       partials, C, G, HW, nch);
+    return lc_launch_status();
+}
+
+extern "C" int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials,
+                                  const float* gamma, const float* beta, const float* scale,
+                                  const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B,
+                                  int C, int H, int W, int G, float eps, int act_silu,
+                                  lc_stream_t s) {
+    if (!x || !y || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
+    const long long HW = (long long)H * W;
+    const int nch = gn_chunks((long long)(C / G) * HW);
+    int slabs = (int)((HW + 4095) / 4096);  // >= 4096 elements per block
+    if (slabs < 1) slabs = 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C, B), dim3(256), 0, lc_s(s), x,
+                       (long long)x_bs, partials, gamma, beta, scale, shift, (long long)ss_bs, y,
+                       (long long)y_bs, C, G, HW, nch, eps, act_silu);
+    return lc_launch_status();
+}

@@ -1,0 +1,120 @@
+"""GaussianDiffusion base -- API mirror of the reference's lidargen/models/diffusion/base.py:9-165
+(constructor arguments, `device`, `randn`/`randn_like` RNG contract, `p_loss`, `forward`)."""
+from __future__ import annotations
+
+from typing import List, Literal
+
+import torch
+from torch import nn
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model: nn.Module, condition_model: nn.Module = None,
+                 sampling: Literal["ddpm", "ddim"] = "ddpm",
+                 prediction_type: Literal["eps", "v", "x_0"] = "eps",
+                 loss_type="l2", num_training_steps: int = 1000, noise_schedule: str = "linear",
+                 min_snr_loss_weight: bool = True, min_snr_gamma: float = 5.0,
+                 sampling_resolution=None, clip_sample: bool = True,
+                 clip_sample_range: float = 1):
+        super().__init__()
+        self.model = model
+        self.condition_model = condition_model
+        self.sampling = sampling
+        self.num_training_steps = num_training_steps
+        self.objective = prediction_type
+        self.noise_schedule = noise_schedule
+        self.min_snr_loss_weight = min_snr_loss_weight
+        self.min_snr_gamma = min_snr_gamma
+        self.clip_sample = clip_sample
+        self.clip_sample_range = clip_sample_range
+        losses = {"l2": nn.MSELoss, "l1": nn.L1Loss, "huber": nn.SmoothL1Loss}
+        if isinstance(loss_type, nn.Module):
+            self.criterion = loss_type
+        elif loss_type in losses:
+            self.criterion = losses[loss_type](reduction="none")
+        else:
+            raise ValueError(f"invalid criterion: {loss_type}")
+        if hasattr(self.criterion, "reduction"):
+            assert self.criterion.reduction == "none"
+        assert hasattr(self.model, "in_channels")
+        if sampling_resolution is None:
+            assert hasattr(self.model, "resolution")
+            self.sampling_shape = (self.model.in_channels, *self.model.resolution)
+        else:
+            assert len(sampling_resolution) == 2
+            self.sampling_shape = (self.model.in_channels, *sampling_resolution)
+        self.setup_parameters()
+        self.register_buffer("_dummy", torch.tensor([]))
+
+    @property
+    def device(self):
+        return self._dummy.device
+
+    # RNG contract (reference base.py:73-96): None -> global generator; a Generator -> one
+    # stream; a list of B generators -> sample i depends only on generator i (shard invariant).
+    # CPU generators are honoured on the host and the draw is uploaded, so a CPU-seeded run of
+    # this GPU path consumes exactly the numbers the reference's CPU run does.
+    def randn(self, *shape, rng: List[torch.Generator] | torch.Generator | None = None, **kwargs):
+        device = torch.device(kwargs.pop("device", "cpu"))
+
+        def draw(shp, g):
+            if g is not None and g.device.type != device.type:
+                return torch.randn(*shp, generator=g, device=g.device, **kwargs).to(device)
+            return torch.randn(*shp, generator=g, device=device, **kwargs)
+
+        if rng is None or isinstance(rng, torch.Generator):
+            return draw(shape, rng)
+        if isinstance(rng, list):
+            assert len(rng) == shape[0]
+            return torch.stack([draw(shape[1:], r) for r in rng])
+        raise ValueError(f"invalid rng: {rng}")
+
+    def randn_like(self, x, rng=None):
+        return self.randn(*x.shape, rng=rng, device=x.device, dtype=x.dtype)
+
+    def setup_parameters(self) -> None:
+        raise NotImplementedError
+
+    def sample_timesteps(self, batch_size: int, device) -> torch.Tensor:
+        raise NotImplementedError
+
+    def get_network_condition(self, steps):
+        raise NotImplementedError
+
+    def get_target(self, x_0, steps, noise):
+        raise NotImplementedError
+
+    def get_loss_weight(self, steps):
+        raise NotImplementedError
+
+    def q_step_from_x_0(self, x_0, steps, rng=None):
+        raise NotImplementedError
+
+    def q_step(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def p_step(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def _masked_loss(self, prediction, target, loss_mask, steps):
+        loss = self.criterion(prediction, target)
+        loss = (loss * loss_mask).flatten(1).sum(1, keepdim=True)
+        denom = loss_mask.flatten(1).sum(1, keepdim=True)
+        loss = loss / denom.add(1e-8)
+        return (loss * self.get_loss_weight(steps)).mean()
+
+    def p_loss(self, x_0, steps, loss_mask=None):
+        """Loss VALUE of one denoising step (reference base.py:124-143).  The HIP denoiser has no
+        backward pass yet (training = SURVEY.md §8f-4), so this is evaluation-only."""
+        loss_mask = torch.ones_like(x_0) if loss_mask is None else loss_mask
+        x_t, noise = self.q_step_from_x_0(x_0, steps)
+        with torch.no_grad():
+            prediction = self.model(x_t, self.get_network_condition(steps))
+        return self._masked_loss(prediction, self.get_target(x_0, steps, noise), loss_mask, steps)
+
+    def forward(self, x_0, loss_mask=None):
+        steps = self.sample_timesteps(x_0.shape[0], x_0.device)
+        return self.p_loss(x_0, steps, loss_mask)

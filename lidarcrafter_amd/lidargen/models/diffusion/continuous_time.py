@@ -1,0 +1,195 @@
+"""Continuous-time Gaussian diffusion (https://arxiv.org/abs/2107.00630) on the HIP hot path.
+
+API mirror of the reference's lidargen/models/diffusion/continuous_time.py:66-330
+(constructor, log_snr, get_*, q_step*, p_step, sample, repaint), with the sampling loop
+re-designed for the GPU:
+  * all schedule scalars of a run are tabulated once on the host ([S,B,8], schedules.py) --
+    the reference launches ~20 tiny kernels per step for them;
+  * the time-embedding MLP and every AdaGN projection are evaluated for ALL steps in one batch
+    before the loop (they depend on the step index only);
+  * x0-prediction, clamp and the DDPM/DDIM update are one fused kernel (lc_pstep_fwd) that
+    writes x_s straight into the denoiser's resident input buffer;
+  * no host<->device synchronisation inside the loop (CPU generators excepted, see base.randn).
+"""
+from __future__ import annotations
+
+from typing import List, Literal
+
+import torch
+from torch import nn
+from tqdm.auto import tqdm
+
+from lidarcrafter_amd import ops as K
+
+from . import base, schedules
+
+
+class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
+    # The reference draws randn_like() in p_step even for DDIM eta=0 where it is multiplied by 0
+    # (continuous_time.py:229).  Set True to also advance the generators in that case.
+    advance_rng_when_unused = False
+
+    def __init__(self, model: nn.Module, condition_model: nn.Module = None,
+                 prediction_type: Literal["eps", "v", "x_0"] = "eps", loss_type="l2",
+                 noise_schedule: str = "cosine", min_snr_loss_weight: bool = True,
+                 min_snr_gamma: float = 5.0, sampling_resolution=None, clip_sample: bool = True,
+                 clip_sample_range: float = 1, image_d: float = None, noise_d_low: float = None,
+                 noise_d_high: float = None):
+        self.image_d, self.noise_d_low, self.noise_d_high = image_d, noise_d_low, noise_d_high
+        super().__init__(model=model, condition_model=condition_model, sampling="ddpm",
+                         prediction_type=prediction_type, loss_type=loss_type,
+                         num_training_steps=None, noise_schedule=noise_schedule,
+                         min_snr_loss_weight=min_snr_loss_weight, min_snr_gamma=min_snr_gamma,
+                         sampling_resolution=sampling_resolution, clip_sample=clip_sample,
+                         clip_sample_range=clip_sample_range)
+
+    # ---- schedule ------------------------------------------------------------------------------
+    def setup_parameters(self) -> None:
+        self._schedule = schedules.make_schedule(self.noise_schedule, self.image_d,
+                                                 self.noise_d_low, self.noise_d_high)
+
+    def log_snr(self, t: torch.Tensor) -> torch.Tensor:
+        return self._schedule(t)[:, None, None, None]
+
+    def sample_timesteps(self, batch_size: int, device) -> torch.Tensor:
+        return torch.rand(batch_size, device=device, dtype=torch.float32)
+
+    def get_network_condition(self, steps):
+        return self.log_snr(steps)[:, 0, 0, 0]
+
+    def get_target(self, x_0, step_t, noise):
+        if self.objective == "eps":
+            return noise
+        if self.objective == "x_0":
+            return x_0
+        if self.objective == "v":
+            alpha, sigma = schedules.alpha_sigma(self.log_snr(step_t))
+            return alpha * noise - sigma * x_0
+        raise ValueError(f"invalid objective {self.objective}")
+
+    def get_loss_weight(self, steps):
+        snr = self.log_snr(steps).exp()
+        clipped = snr.clamp(max=self.min_snr_gamma) if self.min_snr_loss_weight else snr.clone()
+        if self.objective == "eps":
+            return clipped / snr
+        if self.objective == "x_0":
+            return clipped
+        if self.objective == "v":
+            return clipped / (snr + 1)
+        raise ValueError(f"invalid objective {self.objective}")
+
+    # ---- forward process (elementwise, off the hot path) ---------------------------------------
+    def q_step_from_x_0(self, x_0, step_t, rng=None):
+        noise = self.randn_like(x_0, rng=rng)
+        alpha, sigma = schedules.alpha_sigma(self.log_snr(step_t))
+        return x_0 * alpha + noise * sigma, noise
+
+    def q_step(self, x_s, step_t, step_s, rng=None):
+        a_t, s_t = schedules.alpha_sigma(self.log_snr(step_t))
+        a_s, s_s = schedules.alpha_sigma(self.log_snr(step_s))
+        a_ts = a_t / a_s
+        var = s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)
+        return x_s * a_ts + var.sqrt() * self.randn_like(x_s, rng=rng)
+
+    # ---- reverse process -----------------------------------------------------------------------
+    def _objective_id(self):
+        if self.objective not in schedules.OBJECTIVES:
+            raise ValueError(f"invalid objective {self.objective}")
+        return schedules.OBJECTIVES[self.objective]
+
+    def _clip(self):
+        return float(self.clip_sample_range) if self.clip_sample else 0.0
+
+    def _noise_for(self, x_t, rng, mode, ddim_eta):
+        if mode == "ddpm" or ddim_eta != 0.0:
+            return self.randn_like(x_t, rng=rng)
+        if self.advance_rng_when_unused:
+            self.randn_like(x_t, rng=rng)
+        return None
+
+    def _predict(self, x_t, log_snr_t, time_features=None):
+        if time_features is not None:
+            return self.model(x_t, log_snr_t, time_features=time_features)
+        return self.model(x_t, log_snr_t)
+
+    @torch.inference_mode()
+    def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",
+               ddim_eta: float = 0.0):
+        if mode not in schedules.MODES:
+            raise ValueError(f"invalid mode {mode}")
+        lam_t = self._schedule(step_t.float())
+        lam_s = self._schedule(step_s.float())
+        coef = schedules.step_coefficients(lam_t, lam_s, mode, ddim_eta, self._clip())
+        pred = self._predict(x_t, lam_t.to(x_t.device))
+        noise = self._noise_for(x_t, rng, mode, ddim_eta)
+        return K.pstep(x_t, pred, noise, coef.to(x_t.device), self._objective_id(),
+                       schedules.MODES[mode])
+
+    def _plan(self, batch_size, num_steps, mode, ddim_eta, device):
+        """Host-side tables for a whole run: log-SNR rows [S*B] and coefficients [S,B,8]."""
+        if mode not in schedules.MODES:
+            raise ValueError(f"invalid mode {mode}")
+        t = torch.linspace(1.0, 0.0, num_steps + 1)
+        lam = self._schedule(t)
+        coef = schedules.step_coefficients(lam[:-1], lam[1:], mode, ddim_eta, self._clip())
+        coef = coef[:, None, :].expand(num_steps, batch_size, 8).contiguous().to(device)
+        lam_rows = lam[:-1, None].expand(num_steps, batch_size).contiguous().to(device)
+        tf_all = None
+        if hasattr(self.model, "time_features"):
+            tf_all = self.model.time_features(lam_rows.reshape(-1))
+        return lam_rows, coef, tf_all
+
+    def _resident_x(self, x):
+        """Place x in the denoiser's persistent input buffer when it has one."""
+        if hasattr(self.model, "_input_buffer"):
+            slot = self.model._input_buffer(x.shape[0], x)[:, : x.shape[1]]
+            return K.copy_into(slot, x)
+        return x.clone()
+
+    @torch.inference_mode()
+    def sample(self, batch_size: int, num_steps: int, progress: bool = True, rng=None,
+               return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",
+               ddim_eta: float = 0.0):
+        x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
+        out = [x.clone()] if return_all else None
+        lam_rows, coef, tf_all = self._plan(batch_size, num_steps, mode, ddim_eta, self.device)
+        x = self._resident_x(x)
+        B, obj, mid = batch_size, self._objective_id(), schedules.MODES[mode]
+        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+            tf = None if tf_all is None else tuple(a[i * B:(i + 1) * B] for a in tf_all)
+            pred = self._predict(x, lam_rows[i], tf)
+            noise = self._noise_for(x, rng, mode, ddim_eta)
+            K.pstep(x, pred, noise, coef[i], obj, mid, out=x)  # in place, resident
+            if return_all:
+                out.append(x.clone())
+        return torch.stack(out) if return_all else x.clone()
+
+    @torch.inference_mode()
+    def repaint(self, known, mask, num_steps, num_resample_steps: int = 1, jump_length: int = 1,
+                progress: bool = True, rng=None, return_all: bool = False):
+        """RePaint (https://arxiv.org/abs/2201.09865), reference continuous_time.py:262-330."""
+        assert num_resample_steps > 0 and jump_length > 0
+        B = known.shape[0]
+        x_t = self.randn(B, *self.sampling_shape, rng=rng, device=self.device)
+        steps = torch.linspace(1, 0, num_steps + 1, device=self.device)[None].repeat_interleave(B, 0)
+        out = [x_t] if return_all else None
+        x_s = x_t
+        for i in tqdm(range(num_steps), desc="RePaint", leave=False, disable=not progress):
+            for j in range(num_resample_steps):
+                interp = torch.linspace(0, 1, jump_length + 1, device=self.device)
+                r = steps[:, [i]] + interp[None] * (steps[:, [i + 1]] - steps[:, [i]])
+                x = x_t
+                for k in range(jump_length):
+                    known_s, _ = self.q_step_from_x_0(known, r[:, k + 1], rng=rng)
+                    unknown_s = self.p_step(x, r[:, k], r[:, k + 1], rng=rng)
+                    x = mask * known_s + (1 - mask) * unknown_s
+                x_s = x
+                if return_all:
+                    out.append(x_s)
+                if i == num_steps - 1 or j == num_resample_steps - 1:
+                    x_t = x
+                    break
+                for k in range(jump_length, 0, -1):
+                    x = self.q_step(x, r[:, k - 1], r[:, k], rng=rng)
+                x_t = x
+        return torch.stack(out) if return_all else x_s

@@ -1,0 +1,114 @@
+"""Model factory -- API mirror of the reference's lidargen/utils/inference.py
+(load_model_duffusion_training :261-344, setup_model :28-105, setup_rng :460-461).  This is the
+"plugin boundary" of the reference: tools/generate/*.py and tools/evaluation/sample_and_save_*.py
+obtain (ddpm, model, lidar_utils) here, so swapping the `lidargen` package swaps in the HIP path."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..models.diffusion import (CondContinuousTimeGaussianDiffusion,
+                                ContinuousTimeGaussianDiffusion, DiscreteTimeGaussianDiffusion)
+from ..models.unets import __all__ as __all_unets__
+from .configs import __all__
+from .lidar import LiDARUtility, get_linear_ray_angles
+
+
+def count_parameters(model: torch.nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def _in_channels(cfg) -> int:
+    n = int(bool(cfg.data.train_depth)) + int(bool(cfg.data.train_reflectance))
+    if hasattr(cfg, "condition_model") and getattr(cfg.diffusion, "cond_mode", None) == "concat":
+        n += cfg.condition_model.params["out_channels"]
+    return n
+
+
+def _build_denoiser(cfg):
+    arch = cfg.model.architecture
+    if arch not in __all_unets__:
+        raise NotImplementedError(f"architecture {arch!r} is outside the hot path (SURVEY.md §2)")
+    model = __all_unets__[arch](in_channels=_in_channels(cfg), resolution=cfg.data.resolution,
+                                **cfg.model.params)
+    if "spherical" in cfg.data.projection:
+        model.coords = get_linear_ray_angles(H=cfg.data.resolution[0], W=cfg.data.resolution[1],
+                                             fov_up=cfg.data.fov_up, fov_down=cfg.data.fov_down)
+    elif "unfolding" in cfg.data.projection:
+        model.coords = F.interpolate(torch.load(f"data/{cfg.data.dataset}/unfolding_angles.pth"),
+                                     size=cfg.data.resolution, mode="nearest-exact")
+    else:
+        raise ValueError(f"Unknown: {cfg.data.projection}")
+    return model
+
+
+def _build_diffusion(cfg, model):
+    has_cond = hasattr(cfg, "condition_model")
+    cond = (__all_unets__[cfg.condition_model.architecture](**cfg.condition_model.params)
+            if has_cond else nn.Identity())
+    d = cfg.diffusion
+    if d.timestep_type == "discrete":
+        return DiscreteTimeGaussianDiffusion(model=model, loss_type=d.loss_type,
+                                             num_training_steps=d.num_training_steps,
+                                             prediction_type=d.prediction_type,
+                                             noise_schedule=d.noise_schedule)
+    if d.timestep_type != "continuous":
+        raise ValueError(f"Unknown: {d.timestep_type}")
+    if not has_cond:
+        return ContinuousTimeGaussianDiffusion(model=model, condition_model=cond,
+                                               prediction_type=d.prediction_type,
+                                               loss_type=d.loss_type,
+                                               noise_schedule=d.noise_schedule)
+    return CondContinuousTimeGaussianDiffusion(model=model, condition_model=cond,
+                                               loss_type=d.loss_type,
+                                               prediction_type=d.prediction_type,
+                                               noise_schedule=d.noise_schedule,
+                                               cond_mode=getattr(d, "cond_mode", None),
+                                               w_loss_weight=getattr(d, "w_loss_weight", False))
+
+
+def _lidar_utils(cfg, ddpm):
+    lu = LiDARUtility(resolution=cfg.data.resolution, depth_format=cfg.data.depth_format,
+                      min_depth=cfg.data.min_depth, max_depth=cfg.data.max_depth,
+                      ray_angles=ddpm.model.coords)
+    return lu.eval()
+
+
+def load_model_duffusion_training(cfg: object):
+    """-> (ddpm, model, lidar_utils) or, when cfg.resume is a checkpoint path,
+    (ddpm, model, lidar_utils, global_step, optimizer_state, lr_scheduler_state)."""
+    model = _build_denoiser(cfg)
+    ddpm = _build_diffusion(cfg, model)
+    lidar_utils = _lidar_utils(cfg, ddpm)
+    ckpt_path = getattr(cfg, "resume", None)
+    if ckpt_path is None:
+        return ddpm, model, lidar_utils
+    ckpt = torch.load(ckpt_path, map_location="cpu")
+    ddpm.load_state_dict(ckpt["ema_weights"])
+    ddpm.eval()
+    return ddpm, model, lidar_utils, ckpt["global_step"], ckpt["optimizer"], ckpt["lr_scheduler"]
+
+
+def setup_model(cfg: str, ckpt, device="cpu", ema: bool = True, show_info: bool = True,
+                compile: bool = False):
+    if isinstance(ckpt, (str, Path)):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    cfg = __all__[cfg](**ckpt["cfg"])
+    model = _build_denoiser(cfg)
+    ddpm = _build_diffusion(cfg, model)
+    ddpm.load_state_dict(ckpt["ema_weights"] if ema else ckpt["weights"])
+    ddpm.eval().to(device)
+    # `compile` is accepted for signature parity; the denoiser already runs hand-written kernels.
+    lidar_utils = _lidar_utils(cfg, ddpm).to(device)
+    if show_info:
+        print(f"resolution: {model.resolution}", f"model: {model.__class__.__name__}",
+              f"ddpm: {ddpm.__class__.__name__}", f'#steps:  {ckpt["global_step"]:,}',
+              f"#params: {count_parameters(ddpm):,}", sep="\n")
+    return ddpm, lidar_utils, cfg
+
+
+def setup_rng(seeds: list[int], device):
+    return [torch.Generator(device=device).manual_seed(i) for i in seeds]

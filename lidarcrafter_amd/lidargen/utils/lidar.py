@@ -1,0 +1,89 @@
+"""Range-image utilities -- API mirror of the reference's lidargen/utils/lidar.py
+(get_linear_ray_angles :22-32, LiDARUtility :34-132, save_points :135-140).
+Once-per-sample pre/post-processing on [B,1,H,W] tensors (not in the denoising loop)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _angle_grid(H, W, el_hi, el_lo, device="cpu"):
+    el = (1 - torch.arange(H, device=device) / H) * (el_hi - el_lo) + el_lo
+    az = (1 - torch.arange(W, device=device) / W) * 360 - 180
+    el, az = torch.meshgrid([el, az], indexing="ij")
+    return torch.stack([el, az])[None].deg2rad()
+
+
+def get_hdl64e_linear_ray_angles(H: int = 64, W: int = 2048, device="cpu"):
+    return _angle_grid(H, W, 3, -25, device)
+
+
+def get_linear_ray_angles(H: int = 64, W: int = 2048, fov_up=10, fov_down=-30, device="cpu"):
+    return _angle_grid(H, W, fov_up, fov_down, device)
+
+
+class LiDARUtility(nn.Module):
+    def __init__(self, resolution, depth_format, min_depth: float, max_depth: float,
+                 ray_angles: torch.Tensor = None):
+        super().__init__()
+        assert depth_format in ("log_depth", "inverse_depth", "depth")
+        self.resolution, self.depth_format = resolution, depth_format
+        self.min_depth, self.max_depth = min_depth, max_depth
+        if ray_angles is None:
+            raise NotImplementedError
+        assert ray_angles.ndim == 4 and ray_angles.shape[1] == 2
+        ray_angles = F.interpolate(ray_angles, size=self.resolution, mode="nearest-exact")
+        self.register_buffer("ray_angles", ray_angles.float())
+
+    @staticmethod
+    def denormalize(x):
+        return (x + 1) / 2
+
+    @staticmethod
+    def normalize(x):
+        return x * 2 - 1
+
+    def get_mask(self, metric):
+        return ((metric > self.min_depth) & (metric < self.max_depth)).float()
+
+    @torch.no_grad()
+    def to_xyz(self, metric):
+        assert metric.dim() == 4
+        phi, theta = self.ray_angles[:, [0]], self.ray_angles[:, [1]]
+        xyz = torch.cat((metric * phi.cos() * theta.cos(), metric * phi.cos() * theta.sin(),
+                         metric * phi.sin()), dim=1)
+        return xyz * self.get_mask(metric)
+
+    @torch.no_grad()
+    def convert_depth(self, metric, mask=None, depth_format: str = None):
+        fmt = self.depth_format if depth_format is None else depth_format
+        mask = self.get_mask(metric) if mask is None else mask
+        if fmt == "log_depth":
+            n = torch.log2(metric + 1) / np.log2(self.max_depth + 1)
+        elif fmt == "inverse_depth":
+            n = self.min_depth / metric.add(1e-8)
+        elif fmt == "depth":
+            n = metric.div(self.max_depth)
+        else:
+            raise ValueError
+        return n.clamp(0, 1) * mask
+
+    @torch.no_grad()
+    def revert_depth(self, normalized, image_format: str = None):
+        fmt = self.depth_format if image_format is None else image_format
+        if fmt == "log_depth":
+            metric = torch.exp2(normalized * np.log2(self.max_depth + 1)) - 1
+        elif fmt == "inverse_depth":
+            metric = self.min_depth / normalized.add(1e-8)
+        elif fmt == "depth":
+            metric = normalized.mul(self.max_depth)
+        else:
+            raise ValueError
+        return metric * self.get_mask(metric)
+
+
+@torch.no_grad()
+def save_points(tensor, fp):
+    np.savetxt(fp, tensor.detach().cpu().numpy())

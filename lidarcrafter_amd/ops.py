@@ -1,0 +1,296 @@
+"""Tensor-level wrappers over the C ABI (include/lidarcrafter_hip.h).
+
+PyTorch is used here only as the owner of device memory and streams: every function below takes
+torch CUDA tensors, checks layout, and hands raw device pointers + sizes + the current HIP stream
+to liblidarcrafter_hip.so.  No function has a CPU / eager-PyTorch fallback: a non-CUDA tensor or a
+missing library raises.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Optional
+
+import torch
+
+from ._lib import check, lib
+
+_F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"lidarcrafter_amd.ops: `{name}` must be a CUDA(HIP) tensor -- the hot "
+                           "path has no CPU fallback (oracle/ holds the CPU restatement for tests)")
+    if t.dtype != _F32:
+        raise TypeError(f"`{name}` must be float32, got {t.dtype}")
+
+
+def _bs4(t: torch.Tensor, name: str) -> int:
+    """Batch stride (elements) of a [B,C,H,W] tensor whose inner [C,H,W] block is contiguous."""
+    _req(t, name)
+    if t.dim() != 4:
+        raise ValueError(f"`{name}` must be [B,C,H,W], got {tuple(t.shape)}")
+    B, C, H, W = t.shape
+    st = t.stride()
+    inner_ok = (W == 1 or st[3] == 1) and (H == 1 or st[2] == W) and (C == 1 or st[1] == H * W)
+    if not inner_ok:
+        raise ValueError(f"`{name}`: inner [C,H,W] block must be contiguous, strides={st}")
+    return st[0] if B > 1 else C * H * W
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------ conv
+class PackedConv:
+    """Packed copy wp[tap][Cip][Cop] of an OIHW conv weight, rebuilt when the parameter changes."""
+
+    __slots__ = ("wp", "Co", "Ci", "ks", "_key")
+
+    def __init__(self):
+        self.wp = None
+        self._key = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        _req(weight, "weight")
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        if key != self._key:
+            w = weight.detach()
+            if w.dim() == 3:  # Conv1d 1x1 [Co, Ci, 1]
+                w = w.unsqueeze(-1)
+            Co, Ci, kh, kw = w.shape
+            if kh != kw or kh not in (1, 3):
+                raise ValueError(f"only 1x1 / 3x3 kernels, got {tuple(w.shape)}")
+            n = lib().lc_packed_conv_weight_elems(Co, Ci, kh)
+            wp = torch.empty(n, device=w.device, dtype=_F32)
+            check(lib().lc_pack_conv_weight(w.contiguous().data_ptr(), wp.data_ptr(), Co, Ci, kh,
+                                            _stream()), "lc_pack_conv_weight")
+            self.wp, self.Co, self.Ci, self.ks, self._key = wp, Co, Ci, kh, key
+        return self.wp
+
+
+def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
+                bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, out_scale: float = 1.0,
+                tile_cfg: int = 0) -> torch.Tensor:
+    """y = (conv_ring(x, W) + bias [+ res]) * out_scale.  ops.py:149-173 of the reference."""
+    x_bs = _bs4(x, "x")
+    wp = packed.get(weight)
+    B, Ci, H, W = x.shape
+    if Ci != packed.Ci:
+        raise ValueError(f"conv: input has {Ci} channels, weight expects {packed.Ci}")
+    Co = packed.Co
+    if out is None:
+        out = torch.empty((B, Co, H, W), device=x.device, dtype=_F32)
+    y_bs = _bs4(out, "out")
+    if tuple(out.shape) != (B, Co, H, W):
+        raise ValueError(f"conv: out shape {tuple(out.shape)} != {(B, Co, H, W)}")
+    r_bs = 0
+    if res is not None:
+        r_bs = _bs4(res, "res")
+        if tuple(res.shape) != (B, Co, H, W):
+            raise ValueError("conv: residual shape mismatch")
+    if bias is not None:
+        _req(bias, "bias")
+    check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res), r_bs,
+                                   out.data_ptr(), y_bs, B, Ci, Co, H, W, packed.ks,
+                                   float(out_scale), int(tile_cfg), _stream()),
+          "lc_conv2d_ring_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------ norm
+_gn_scratch = {}
+
+
+def _partials(dev, n: int) -> torch.Tensor:
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    buf = _gn_scratch.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 16), device=dev, dtype=torch.float64)
+        _gn_scratch[key] = buf
+    return buf
+
+
+def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=None, shift=None,
+              act_silu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+affine) (+ (1+scale)*h+shift) (+SiLU).  scale/shift: [B, C] views (row stride
+    may exceed C, e.g. the two halves of one [B, 2C] AdaGN projection)."""
+    x_bs = _bs4(x, "x")
+    B, C, H, W = x.shape
+    if C % G:
+        raise ValueError(f"groupnorm: C={C} not divisible by G={G}")
+    if out is None:
+        out = torch.empty((B, C, H, W), device=x.device, dtype=_F32)
+    y_bs = _bs4(out, "out")
+    ss_bs = 0
+    if scale is not None:
+        _req(scale, "scale"), _req(shift, "shift")
+        if scale.shape != (B, C) or shift.shape != (B, C) or scale.stride(1) != 1 or \
+                shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+            raise ValueError("groupnorm: scale/shift must be [B,C] with unit inner stride")
+        ss_bs = scale.stride(0)
+    n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
+    part = _partials(x.device, n)
+    st = _stream()
+    check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, st),
+          "lc_groupnorm_stats")
+    check(lib().lc_groupnorm_apply(x.data_ptr(), x_bs, part.data_ptr(), _p(gamma), _p(beta),
+                                   _p(scale), _p(shift), ss_bs, out.data_ptr(), y_bs, B, C, H, W,
+                                   G, float(eps), int(act_silu), st), "lc_groupnorm_apply")
+    return out
+
+
+# ------------------------------------------------------------------------------------ resample
+def resample2x(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x_bs = _bs4(x, "x")
+    B, C, H, W = x.shape
+    shape = (B, C, 2 * H, 2 * W) if up else (B, C, H // 2, W // 2)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=_F32)
+    y_bs = _bs4(out, "out")
+    if tuple(out.shape) != shape:
+        raise ValueError("resample: out shape mismatch")
+    check(lib().lc_resample2x_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W,
+                                  1 if up else -1, _stream()), "lc_resample2x_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------ dense
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None,
+           act_in: bool = False, act_out: bool = False) -> torch.Tensor:
+    _req(x, "x"), _req(w, "w")
+    if x.dim() != 2 or not x.is_contiguous() or not w.is_contiguous():
+        raise ValueError("linear: x must be contiguous [M,K], w contiguous [N,K]")
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=x.device, dtype=_F32)
+    check(lib().lc_linear_fwd(x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), M, K, N,
+                              int(act_in), int(act_out), _stream()), "lc_linear_fwd")
+    return y
+
+
+def sinusoid(t: torch.Tensor, channels: int, max_period: float = 10_000.0) -> torch.Tensor:
+    _req(t, "t")
+    t = t.contiguous()
+    y = torch.empty((t.shape[0], channels), device=t.device, dtype=_F32)
+    check(lib().lc_sinusoid_fwd(t.data_ptr(), y.data_ptr(), t.shape[0], channels,
+                                float(max_period), _stream()), "lc_sinusoid_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------ attention
+def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Channel-major attention.  q:[B, heads*dqk, Lq]  k:[B, heads*dqk, Lk0]  v:[B, heads*dv, Lk0]
+    (views with arbitrary batch/channel strides, unit token stride); optional second key/value
+    segment k2/v2 with Lk1 tokens (the 13 layout tokens of ObjectAwareCrossAttention)."""
+    for n_, t_ in (("q", q), ("k", k), ("v", v)):
+        _req(t_, n_)
+        if t_.dim() != 3 or t_.stride(2) != 1:
+            raise ValueError(f"attention: `{n_}` must be [B,C,L] with unit token stride")
+    B, Cq, Lq = q.shape
+    dqk, dv = Cq // heads, v.shape[1] // heads
+    Lk0 = k.shape[2]
+    Lk1 = 0
+    if k2 is not None:
+        _req(k2, "k2"), _req(v2, "v2")
+        Lk1 = k2.shape[2]
+    if out is None:
+        out = torch.empty((B, heads * dv, Lq), device=q.device, dtype=_F32)
+
+    def st(t, d):
+        return (t.stride(0), d * t.stride(1), t.stride(1))
+
+    z = (0, 0, 0)
+    args = [q.data_ptr(), *st(q, dqk), k.data_ptr(), *st(k, dqk), v.data_ptr(), *st(v, dv),
+            _p(k2), *(st(k2, dqk) if k2 is not None else z),
+            _p(v2), *(st(v2, dv) if v2 is not None else z),
+            out.data_ptr(), *st(out, dv), B, heads, Lq, Lk0, Lk1, dqk, dv, float(scale), _stream()]
+    check(lib().lc_attention_fwd(*args), "lc_attention_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------ sampler
+def pstep(x_t, pred, noise, coef, objective: int, mode: int, out=None) -> torch.Tensor:
+    xb, pb = _bs4(x_t, "x_t"), _bs4(pred, "pred")
+    B, C, H, W = x_t.shape
+    if out is None:
+        out = torch.empty((B, C, H, W), device=x_t.device, dtype=_F32)
+    ob = _bs4(out, "out")
+    nb = _bs4(noise, "noise") if noise is not None else 0
+    _req(coef, "coef")
+    if tuple(coef.shape) != (B, 8) or not coef.is_contiguous():
+        raise ValueError("pstep: coef must be contiguous [B,8]")
+    check(lib().lc_pstep_fwd(x_t.data_ptr(), xb, pred.data_ptr(), pb, _p(noise), nb,
+                             coef.data_ptr(), out.data_ptr(), ob, B, C * H * W, objective, mode,
+                             _stream()), "lc_pstep_fwd")
+    return out
+
+
+def copy_into(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    db, sb = _bs4(dst, "dst"), _bs4(src, "src")
+    if dst.shape != src.shape:
+        raise ValueError("copy_into: shape mismatch")
+    B, C, H, W = src.shape
+    check(lib().lc_copy_strided(src.data_ptr(), sb, dst.data_ptr(), db, B, C * H * W, _stream()),
+          "lc_copy_strided")
+    return dst
+
+
+def add_scale(a: torch.Tensor, b: torch.Tensor, scale: float, out=None) -> torch.Tensor:
+    ab, bb = _bs4(a, "a"), _bs4(b, "b")
+    B, C, H, W = a.shape
+    if out is None:
+        out = torch.empty((B, C, H, W), device=a.device, dtype=_F32)
+    ob = _bs4(out, "out")
+    check(lib().lc_add_scale(a.data_ptr(), ab, b.data_ptr(), bb, out.data_ptr(), ob, B, C * H * W,
+                             float(scale), _stream()), "lc_add_scale")
+    return out
+
+
+# ------------------------------------------------------------------------------------ geometry
+def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down: float,
+                   min_depth: float, max_depth: float, return_cells: bool = False):
+    """[N,4] (x,y,z,intensity) -> image [H,W,6], winner int32 [H,W] (+ cells int32 [N,2])."""
+    _req(points, "points")
+    if points.dim() != 2 or points.shape[1] != 4 or not points.is_contiguous():
+        raise ValueError("project_points: points must be contiguous [N,4]")
+    N = points.shape[0]
+    dev = points.device
+    zbuf = torch.empty(H * W, device=dev, dtype=torch.int64)
+    img = torch.empty((H, W, 6), device=dev, dtype=_F32)
+    win = torch.empty((H, W), device=dev, dtype=torch.int32)
+    cells = torch.empty((N, 2), device=dev, dtype=torch.int32) if return_cells else None
+    check(lib().lc_project_points(points.data_ptr(), N, H, W, float(fov_up), float(fov_down),
+                                  float(min_depth), float(max_depth), zbuf.data_ptr(),
+                                  img.data_ptr(), win.data_ptr(), _p(cells), _stream()),
+          "lc_project_points")
+    return (img, win, cells) if return_cells else (img, win)
+
+
+def points_in_boxes_mask(points: torch.Tensor, boxes: torch.Tensor, margin: float) -> torch.Tensor:
+    _req(points, "points"), _req(boxes, "boxes")
+    points, boxes = points.contiguous(), boxes.contiguous()
+    out = torch.empty((boxes.shape[0], points.shape[0]), device=points.device, dtype=torch.int32)
+    check(lib().lc_points_in_boxes_mask(boxes.data_ptr(), boxes.shape[0], points.data_ptr(),
+                                        points.shape[0], float(margin), out.data_ptr(), _stream()),
+          "lc_points_in_boxes_mask")
+    return out
+
+
+def points_in_boxes_index(points: torch.Tensor, boxes: torch.Tensor, margin: float) -> torch.Tensor:
+    _req(points, "points"), _req(boxes, "boxes")
+    points, boxes = points.contiguous(), boxes.contiguous()
+    B, M, _ = points.shape
+    out = torch.empty((B, M), device=points.device, dtype=torch.int32)
+    check(lib().lc_points_in_boxes_index(boxes.data_ptr(), points.data_ptr(), B, boxes.shape[1], M,
+                                         float(margin), out.data_ptr(), _stream()),
+          "lc_points_in_boxes_index")
+    return out

@@ -1,0 +1,215 @@
+"""Generate golden vectors by running the REFERENCE (imported read-only from /root/reference).
+
+Run in the build container only:   python tests/golden/make_fixtures.py [section ...]
+Outputs tests/golden/*.npz (committed).  Inputs are regenerated from seeds by the tests
+(lidarcrafter_amd.testing.seeded_randn / seeded_fill), so the files hold mostly OUTPUTS.
+Nothing here travels to the GPU box except the .npz data files.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_import as R  # noqa: E402
+
+R.install()
+from lidarcrafter_amd.testing import seeded_fill, seeded_randn, synth_points  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path)/1024:.1f} KiB  keys={list(out)}")
+
+
+# ------------------------------------------------------------------------------------------
+def sec_ops():
+    ops = R.ref("models.unets.ops")
+    enc = R.ref("models.unets.encoding")
+    lidar = R.ref("utils.lidar")
+    eu = R.ref("models.unets.efficient_unet")
+    out = {}
+    with torch.no_grad():
+        # ring conv 3x3 and plain 1x1 (ops.py:149-173)
+        c3 = seeded_fill(ops.Conv2d(5, 7, 3, 1, 1, ring=True), salt=1)
+        x = seeded_randn(2, 5, 4, 16, seed=11)
+        out["conv3_y"] = c3(x)
+        c1 = seeded_fill(ops.Conv2d(5, 7, 1, 1, 0), salt=2)
+        out["conv1_y"] = c1(x)
+        # resample (ops.py:52-146)
+        x = seeded_randn(2, 3, 4, 16, seed=12)
+        out["down_y"] = ops.Resample(down=2, ring=True)(x)
+        out["up_y"] = ops.Resample(up=2, ring=True)(x)
+        # GN + AdaGN (ops.py:176-200)
+        x = seeded_randn(2, 16, 4, 8, seed=13)
+        gn = seeded_fill(torch.nn.GroupNorm(8, 16, 1e-6), salt=3)
+        out["gn_y"] = gn(x)
+        ada = seeded_fill(ops.AdaGN(32, 16, 8, 1e-6), salt=4)
+        emb = seeded_randn(2, 32, seed=14)
+        out["adagn_y"] = ada(x, emb)
+        # sinusoid of log-SNR values (ops.py:14-29)
+        lam = torch.tensor([-15.0, -3.25, 0.0, 7.5, 15.0])
+        out["sin_y"] = ops.SinusoidalPositionalEmbedding(64)(lam)
+        # Fourier features on linear ray angles (encoding.py:120-146, lidar.py:22-32)
+        coords = lidar.get_linear_ray_angles(8, 64, 10.0, -30.0)
+        out["coords_8x64"] = coords
+        out["fourier_8x64"] = enc.FourierFeatures((8, 64))(coords)
+        # blocks (efficient_unet.py:28-115)
+        x = seeded_randn(2, 32, 4, 8, seed=15)
+        temb = seeded_randn(2, 64, seed=16)
+        rb = seeded_fill(eu.ResidualBlock(32, 32, 64, 8, 1e-6, ring=True), salt=5)
+        out["rb_same_y"] = rb(x, temb)
+        rb2 = seeded_fill(eu.ResidualBlock(32, 16, 64, 8, 1e-6, ring=True), salt=6)
+        out["rb_skip_y"] = rb2(x, temb)
+        sa = seeded_fill(eu.SelfAttentionBlock(32, 4, 1e-6, 8), salt=7).eval()
+        out["sa_y"] = sa(x)
+    save("ops", **out)
+
+
+def _build_uncond(eu, base, res):
+    m = eu.EfficientUNet(2, res, base_channels=base, temb_channels=None,
+                         channel_multiplier=(1, 2, 4, 8), num_residual_blocks=(3, 3, 3, 3),
+                         gn_num_groups=8, gn_eps=1e-6, attn_num_heads=8,
+                         coords_encoding="fourier_features", ring=True)
+    lidar = R.ref("utils.lidar")
+    m.coords = lidar.get_linear_ray_angles(res[0], res[1], 10.0, -30.0)  # inference.py:281-282
+    return seeded_fill(m, salt=100).eval()
+
+
+def sec_unet_small():
+    eu = R.ref("models.unets.efficient_unet")
+    m = _build_uncond(eu, 16, (8, 64))
+    x = seeded_randn(2, 2, 8, 64, seed=21)
+    lam = torch.tensor([-4.0, 2.5])
+    with torch.no_grad():
+        y = m(x, lam)
+    save("unet_small", y=y, nkeys=len(m.state_dict()))
+
+
+def sec_unet_full():
+    eu = R.ref("models.unets.efficient_unet")
+    m = _build_uncond(eu, 64, (32, 1024))
+    x = seeded_randn(1, 2, 32, 1024, seed=22)
+    lam = torch.tensor([-1.5])
+    with torch.no_grad():
+        y = m(x, lam)
+    keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    save("unet_full", y=y, keys=np.array(sorted(f"{k}:{s}" for k, s in keys.items())))
+
+
+def sec_diffusion():
+    df = R.ref("models.diffusion")
+    ct = R.ref("models.diffusion.continuous_time")
+
+    class Stub(torch.nn.Module):
+        resolution = (4, 16)
+        in_channels = 2
+
+        def __init__(self):
+            super().__init__()
+            self.pred = None
+
+        def forward(self, x, c):
+            return self.pred.clone()  # the reference clamps x_0 (== prediction) in place
+
+    out = {}
+    for S in (10, 50):
+        t = torch.linspace(1.0, 0.0, S + 1)
+        lam = ct._log_snr_schedule_cosine(t)[:, 0, 0, 0]
+        a, s = ct._log_snr_to_alpha_sigma(lam)
+        out[f"lam_{S}"], out[f"alpha_{S}"], out[f"sigma_{S}"] = lam, a, s
+    out["lam_linear_10"] = ct._log_snr_schedule_linear(torch.linspace(1.0, 0.0, 11))[:, 0, 0, 0]
+    x_t = seeded_randn(3, 2, 4, 16, seed=31)
+    pred = seeded_randn(3, 2, 4, 16, seed=32)
+    step_t = torch.tensor([1.0, 0.6, 0.1])
+    step_s = torch.tensor([0.9, 0.5, 0.0])
+    for obj in ("eps", "v", "x_0"):
+        stub = Stub()
+        stub.pred = pred
+        ddpm = df.ContinuousTimeGaussianDiffusion(stub, torch.nn.Identity(), prediction_type=obj)
+        for mode, eta in (("ddpm", 0.0), ("ddim", 0.0), ("ddim", 0.5)):
+            rng = [torch.Generator().manual_seed(100 + i) for i in range(3)]
+            out[f"pstep_{obj}_{mode}_{eta}"] = ddpm.p_step(x_t, step_t, step_s, rng=rng,
+                                                           mode=mode, ddim_eta=eta)
+    # discrete tables + p_step (discrete_time.py)
+    for kind in ("linear", "cosine", "sigmoid"):
+        stub = Stub()
+        stub.pred = pred
+        dd = df.DiscreteTimeGaussianDiffusion(stub, None, num_training_steps=50,
+                                              noise_schedule=kind)
+        out[f"disc_{kind}_beta"] = dd.beta[:, 0, 0, 0]
+        out[f"disc_{kind}_abar"] = dd.alpha_bar[:, 0, 0, 0]
+        steps = torch.tensor([49, 20, 0])
+        for mode in ("ddpm", "ddim"):
+            rng = [torch.Generator().manual_seed(200 + i) for i in range(3)]
+            out[f"disc_{kind}_{mode}"] = dd.p_step(x_t, steps, rng=rng, mode=mode)
+    save("diffusion", **out)
+
+
+def sec_trajectory():
+    """C1: 32x1024, DDIM 10 steps, B=1, seeded weights, per-sample CPU generator;
+    plus the same loop on the reduced model with all states kept."""
+    eu = R.ref("models.unets.efficient_unet")
+    df = R.ref("models.diffusion")
+    m = _build_uncond(eu, 16, (8, 64))
+    ddpm = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval()
+    out = {}
+    for mode in ("ddim", "ddpm"):
+        rng = [torch.Generator().manual_seed(i) for i in range(2)]
+        out[f"small_{mode}"] = ddpm.sample(2, 10, progress=False, rng=rng, return_all=True, mode=mode)
+    m = _build_uncond(eu, 64, (32, 1024))
+    ddpm = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval()
+    rng = [torch.Generator().manual_seed(0)]
+    xs = ddpm.sample(1, 10, progress=False, rng=rng, return_all=True, mode="ddim")
+    out["c1_x1"], out["c1_x2"], out["c1_x10"] = xs[1], xs[2], xs[10]
+    out["c1_means"] = xs.flatten(1).mean(1)
+    out["c1_abs_means"] = xs.flatten(1).abs().mean(1)
+    save("trajectory", **out)
+
+
+def sec_lidar():
+    lidar = R.ref("utils.lidar")
+    cm = R.ref("dataset.transforms_3d.common")
+    out = {}
+    ang = lidar.get_linear_ray_angles(8, 64, 10.0, -30.0)
+    lu = lidar.LiDARUtility((8, 64), "log_depth", 1.45, 80.0, ray_angles=ang)
+    metric = seeded_randn(2, 1, 8, 64, seed=41).abs() * 40
+    out["convert_depth"] = lu.convert_depth(metric)
+    nz = torch.rand(2, 1, 8, 64, generator=torch.Generator().manual_seed(42))
+    out["revert_depth"] = lu.revert_depth(nz)
+    out["to_xyz"] = lu.to_xyz(metric)
+    # projection on a seeded synthetic sweep: azimuth U(-pi,pi), elevation
+    # U(-30.5,10.5) deg, range log-U(0.8,95) m, intensity U(0,255)
+    for tag, N, H, W, seed in (("a", 4096, 16, 256, 0), ("b", 34720, 32, 1024, 1)):
+        pts = synth_points(N, seed)
+        img = cm.load_points_as_images(points=pts, scan_unfolding=False, H=H, W=W,
+                                       min_depth=1.45, max_depth=80.0, fov_up=10.0, fov_down=-30.0)
+        out[f"proj_{tag}_depth"] = img[..., 4]
+        out[f"proj_{tag}_mask"] = img[..., 5].astype(np.uint8)
+        out[f"proj_{tag}_x"] = img[..., 0]
+        out[f"proj_{tag}_i"] = img[..., 3]
+    save("lidar", **out)
+
+
+SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(SECTIONS)
+    for n in names:
+        print(f"== {n}")
+        SECTIONS[n]()
