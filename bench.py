@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Benchmark of the denoising hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" = one reverse-diffusion step of the C2 workload of BASELINE.json (EfficientUNet
+`nuscenes-unet-uncond`, 32x1024 range image, DDIM, batch 8 PER GPU, seeded random-init weights,
+synthetic x_T): one denoiser forward + the fused x0/clamp/update kernel, inputs resident in HBM.
+Weak scaling: every rank owns its own batch of 8 samples (global sample index = rank*8 + i); the
+only communication is one RCCL all-gather of the finished frames after the loop.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     -- dominant kernel (3x3 ring conv, fp32 MFMA): algorithmic FLOPs / HIP-event time
+  cpu_baseline -- the CPU oracle (oracle/, torch fp32) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BATCH_PER_GPU = 8
+RES = (32, 1024)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_SAMPLE_STEP = 116.6  # SURVEY.md §8(d), uncond 32x1024 (114.4 conv + 2.15 MHA)
+
+
+def build_ddpm(device):
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as CONFIGS
+
+    cfg = CONFIGS["nuscenes-unet-uncond"]()
+    ddpm, model, lidar_utils = inference.load_model_duffusion_training(cfg)
+    seeded_fill(model, salt=100)  # random-init weights of the named architecture (no checkpoints)
+    return ddpm.eval().to(device), cfg
+
+
+def x_T_for(rank: int, shape):
+    g = [torch.Generator().manual_seed(rank * BATCH_PER_GPU + i) for i in range(BATCH_PER_GPU)]
+    return torch.stack([torch.randn(*shape, generator=r) for r in g])
+
+
+def cpu_baseline(n_steps: int = 2):
+    """Oracle leg: the CPU restatement (checked against the reference's golden vectors) on the
+    same workload, bounded sample, all host cores torch gives us."""
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as CONFIGS
+    from oracle import denoiser as D
+    from oracle import diffusion as DF
+
+    cfg = CONFIGS["nuscenes-unet-uncond"]()
+    ddpm, model, _ = inference.load_model_duffusion_training(cfg)
+    seeded_fill(model, salt=100)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = x_T_for(0, ddpm.sampling_shape)
+    steps = torch.linspace(1.0, 0.0, 51)[None].repeat_interleave(BATCH_PER_GPU, 0)
+    den = lambda a, lam: D.efficient_unet_forward(sd, a, lam)
+    noise = torch.zeros_like(x)
+    DF.p_step(den, x[:1], steps[:1, 0], steps[:1, 1], noise[:1], mode="ddim")  # warm
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        x = DF.p_step(den, x, steps[:, i], steps[:, i + 1], noise, mode="ddim")
+    dt = time.perf_counter() - t0
+    return {"value": n_steps / dt, "unit": "denoising-steps/s (batch 8)",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_steps} DDIM steps of the C2 batch (8x 32x1024) through "
+                      f"oracle.efficient_unet_forward + oracle p_step, torch fp32 CPU, "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if dist_on:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from lidarcrafter_amd import ops as K
+
+    ddpm, cfg = build_ddpm(device)
+    total = args.warmup + args.steps
+    x_T = x_T_for(rank, ddpm.sampling_shape).to(device)
+    st = ddpm.begin_sampling(BATCH_PER_GPU, total, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
+
+    def sync():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ddpm.sampling_step(st)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ddpm.sampling_step(st)
+    frames = st["x"]
+    if dist_on:  # reassemble the generated frames once, after the loop (RCCL all-gather)
+        gathered = [torch.empty_like(frames) for _ in range(world)]
+        dist.all_gather(gathered, frames.contiguous())
+    sync()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(frames).all()
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # second, instrumented pass: HIP events around every launch of the dominant kernel
+        st2 = ddpm.begin_sampling(BATCH_PER_GPU, max(args.steps, 3), rng=None, mode="ddim",
+                                  x_T=x_T)
+        ddpm.sampling_step(st2)
+        torch.cuda.synchronize()
+        K.PROFILE = []
+        n_prof = min(args.steps, 5)
+        for _ in range(n_prof):
+            ddpm.sampling_step(st2)
+        torch.cuda.synchronize()
+        rec, K.PROFILE = K.PROFILE, None
+        fam = {}
+        for name, work, e0, e1 in rec:
+            a = fam.setdefault(name, [0.0, 0.0, 0])
+            a[0] += work
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        w, t, n = fam["conv3x3"]
+        achieved = w / t / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_ring_kernel<KS=3> (all tile instantiations)",
+                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n // n_prof,
+                "avg_launch_us": round(t / n * 1e6, 1),
+                "flop_per_launch": round(w / n),
+                "time_share_per_family_ms_per_step": {
+                    k: round(v[1] / n_prof * 1e3, 3) for k, v in sorted(fam.items())}}
+    if dist_on:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        steps_per_s = world * args.steps / dt
+        line = {
+            "metric": "denoising-steps/sec, nuScenes 32x1024 range image",
+            "value": round(steps_per_s, 3),
+            "unit": "denoising-steps/s (each step = batch of 8 frames per GPU)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: EfficientUNet nuscenes-unet-uncond (31.1M params, seeded "
+                                   "random init), 32x1024, DDIM eta=0, batch 8 per GPU, "
+                                   f"{total}-step schedule ({args.warmup} warmup + {args.steps} timed)",
+                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
+                       "resolution": list(RES), "parallelism": f"dp{world} (no data-path collective)",
+                       "sample_steps_per_s": round(steps_per_s * BATCH_PER_GPU, 2),
+                       "algorithmic_tflops": round(
+                           steps_per_s * BATCH_PER_GPU * GFLOP_PER_SAMPLE_STEP / 1e3, 2)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -231,16 +231,18 @@ int dispatch(int cfg, const ConvArgs& a, hipStream_t st) {
 }
 
 int auto_cfg(int B, int Co, int H, int W) {
+    // Measured on MI355X at batch 8 (devtools/conv_sweep.py, profiles/r01_conv_sweep.txt):
+    //   Co <= 64  : 64co x 128px blocks (cfg 5) reach 106-114 TF, 64x64 (cfg 3) 100-110 TF
+    //   Co >= 128 : 128co x 128px (cfg 4 / 1) reach 108-122 TF when they still give >= 2 blocks
+    //               per CU; otherwise the 64x64 tile (cfg 3) keeps all 256 CUs busy (L3 512->512:
+    //               100 TF vs 56 TF).
     const long long px = (long long)B * H * W;
-    const bool wide = (W % 64 == 0);
-    // blocks each config would launch; want >= ~2 per CU (512) when the problem allows it
     auto blocks = [&](int bn, int pxb) { return ((Co + bn - 1) / bn) * ((px + pxb - 1) / pxb); };
-    if (Co > 64) {
-        if (blocks(128, 128) >= 512) return (wide && H % 2 == 0) ? 1 : 4;
-        return (W % 32 == 0) ? 3 : 3;
+    if (Co > 64 && blocks(128, 128) >= 512) {
+        if (H % 4 == 0 && W % 32 == 0) return 4;
+        if (H % 2 == 0 && W % 64 == 0) return 1;
     }
-    if (wide && H % 4 == 0 && blocks(64, 256) >= 512) return 2;
-    if (wide && H % 2 == 0 && blocks(64, 128) >= 512) return 5;
+    if (Co <= 64 && H % 2 == 0 && W % 64 == 0 && blocks(64, 128) >= 512) return 5;
     return 3;
 }
 

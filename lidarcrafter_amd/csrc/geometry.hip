@@ -113,7 +113,7 @@ extern "C" int lc_project_points(const float* points, int N, int H, int W, float
                                  float fov_down_deg, float min_depth, float max_depth,
                                  uint64_t* zbuf, float* image, int32_t* winner, int32_t* cells,
                                  lc_stream_t s) {
-    if (!points || !zbuf || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
+    if ((!points && N > 0) || !zbuf || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
     if (reinterpret_cast<uintptr_t>(points) & 15) return LC_EINVAL;
     const int HW = H * W;
     // np.deg2rad in float64 then rounded to float32 (oracle/lidar.py mode="f32")

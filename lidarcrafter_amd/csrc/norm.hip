@@ -20,16 +20,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     const float* p = x + b * x_bs + (long long)g * n;
     const long long lo = (long long)chunk * GN_CHUNK;
     const long long hi = (lo + GN_CHUNK < n) ? lo + GN_CHUNK : n;
+    // shifted sums (pivot = first element of the group) -> no cancellation in E[d^2]-E[d]^2
+    const float piv = p[0];
     float s = 0.f, q = 0.f;
     if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
         for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+            f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+            v.x -= piv; v.y -= piv; v.z -= piv; v.w -= piv;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
     } else {
         for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-            const float v = p[i];
+            const float v = p[i] - piv;
             s += v; q += v * v;
         }
     }
@@ -57,11 +60,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     double s = 0.0, q = 0.0;
     for (int i = 0; i < nch; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
     const double n = (double)cpg * (double)HW;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
+    const double dm = s / n;                                   // mean of (x - pivot)
+    double var = q / n - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float mu = (float)mean;
+    const float mu = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
     const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
     const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
     const float sh = shift ? shift[b * ss_bs + c] : 0.0f;

@@ -146,23 +146,42 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
             return K.copy_into(slot, x)
         return x.clone()
 
+    # ---- the sampling loop, exposed step-wise (bench.py times exactly K calls of `sampling_step`)
+    @torch.inference_mode()
+    def begin_sampling(self, batch_size: int, num_steps: int, rng=None,
+                       mode: Literal["ddpm", "ddim"] = "ddpm", ddim_eta: float = 0.0, x_T=None):
+        """Draw x_T (or take it), build the per-run tables, make x resident.  Returns a state dict
+        consumed by `sampling_step`."""
+        x = x_T if x_T is not None else self.randn(batch_size, *self.sampling_shape, rng=rng,
+                                                   device=self.device)
+        x0 = x.clone()
+        lam_rows, coef, tf_all = self._plan(batch_size, num_steps, mode, ddim_eta, self.device)
+        return dict(x=self._resident_x(x), x_T=x0, i=0, n=num_steps, B=batch_size, rng=rng,
+                    mode=mode, eta=ddim_eta, lam=lam_rows, coef=coef, tf=tf_all,
+                    obj=self._objective_id(), mid=schedules.MODES[mode])
+
+    @torch.inference_mode()
+    def sampling_step(self, st: dict) -> torch.Tensor:
+        """One reverse step: denoiser forward + fused x0/clamp/update, in place on the resident x."""
+        i, B, x = st["i"], st["B"], st["x"]
+        tf = None if st["tf"] is None else tuple(a[i * B:(i + 1) * B] for a in st["tf"])
+        pred = self._predict(x, st["lam"][i], tf)
+        noise = self._noise_for(x, st["rng"], st["mode"], st["eta"])
+        K.pstep(x, pred, noise, st["coef"][i], st["obj"], st["mid"], out=x)
+        st["i"] = i + 1
+        return x
+
     @torch.inference_mode()
     def sample(self, batch_size: int, num_steps: int, progress: bool = True, rng=None,
                return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
-        x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
-        out = [x.clone()] if return_all else None
-        lam_rows, coef, tf_all = self._plan(batch_size, num_steps, mode, ddim_eta, self.device)
-        x = self._resident_x(x)
-        B, obj, mid = batch_size, self._objective_id(), schedules.MODES[mode]
-        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-            tf = None if tf_all is None else tuple(a[i * B:(i + 1) * B] for a in tf_all)
-            pred = self._predict(x, lam_rows[i], tf)
-            noise = self._noise_for(x, rng, mode, ddim_eta)
-            K.pstep(x, pred, noise, coef[i], obj, mid, out=x)  # in place, resident
+        st = self.begin_sampling(batch_size, num_steps, rng, mode, ddim_eta)
+        out = [st["x_T"]] if return_all else None
+        for _ in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+            x = self.sampling_step(st)
             if return_all:
                 out.append(x.clone())
-        return torch.stack(out) if return_all else x.clone()
+        return torch.stack(out) if return_all else st["x"].clone()
 
     @torch.inference_mode()
     def repaint(self, known, mask, num_steps, num_resample_steps: int = 1, jump_length: int = 1,

@@ -47,6 +47,31 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+# Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg sets
+# PROFILE to a list; entries are (kernel_family, algorithmic_work, start_event, end_event)).
+PROFILE = None
+
+
+class _Timed:
+    __slots__ = ("name", "work", "e0")
+
+    def __init__(self, name, work):
+        self.name, self.work, self.e0 = name, work, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.name, self.work, self.e0, e1))
+        return False
+
+
 # ------------------------------------------------------------------------------------ conv
 class PackedConv:
     """Packed copy wp[tap][Cip][Cop] of an OIHW conv weight, rebuilt when the parameter changes."""
@@ -98,10 +123,12 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
             raise ValueError("conv: residual shape mismatch")
     if bias is not None:
         _req(bias, "bias")
-    check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res), r_bs,
-                                   out.data_ptr(), y_bs, B, Ci, Co, H, W, packed.ks,
-                                   float(out_scale), int(tile_cfg), _stream()),
-          "lc_conv2d_ring_fwd")
+    ks = packed.ks
+    with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks):
+        check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res), r_bs,
+                                       out.data_ptr(), y_bs, B, Ci, Co, H, W, ks,
+                                       float(out_scale), int(tile_cfg), _stream()),
+              "lc_conv2d_ring_fwd")
     return out
 
 
@@ -139,11 +166,12 @@ def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=
     n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
     part = _partials(x.device, n)
     st = _stream()
-    check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, st),
-          "lc_groupnorm_stats")
-    check(lib().lc_groupnorm_apply(x.data_ptr(), x_bs, part.data_ptr(), _p(gamma), _p(beta),
-                                   _p(scale), _p(shift), ss_bs, out.data_ptr(), y_bs, B, C, H, W,
-                                   G, float(eps), int(act_silu), st), "lc_groupnorm_apply")
+    with _Timed("groupnorm", 12.0 * B * C * H * W):  # bytes: stats read + apply read + write
+        check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, st),
+              "lc_groupnorm_stats")
+        check(lib().lc_groupnorm_apply(x.data_ptr(), x_bs, part.data_ptr(), _p(gamma), _p(beta),
+                                       _p(scale), _p(shift), ss_bs, out.data_ptr(), y_bs, B, C, H,
+                                       W, G, float(eps), int(act_silu), st), "lc_groupnorm_apply")
     return out
 
 
@@ -157,8 +185,9 @@ def resample2x(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None) ->
     y_bs = _bs4(out, "out")
     if tuple(out.shape) != shape:
         raise ValueError("resample: out shape mismatch")
-    check(lib().lc_resample2x_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W,
-                                  1 if up else -1, _stream()), "lc_resample2x_fwd")
+    with _Timed("resample", 4.0 * B * C * H * W * (5.0 if up else 1.25)):
+        check(lib().lc_resample2x_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W,
+                                      1 if up else -1, _stream()), "lc_resample2x_fwd")
     return out
 
 
@@ -213,7 +242,8 @@ def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None,
             _p(k2), *(st(k2, dqk) if k2 is not None else z),
             _p(v2), *(st(v2, dv) if v2 is not None else z),
             out.data_ptr(), *st(out, dv), B, heads, Lq, Lk0, Lk1, dqk, dv, float(scale), _stream()]
-    check(lib().lc_attention_fwd(*args), "lc_attention_fwd")
+    with _Timed("attention", 2.0 * B * heads * Lq * (Lk0 + Lk1) * (dqk + dv)):
+        check(lib().lc_attention_fwd(*args), "lc_attention_fwd")
     return out
 
 
