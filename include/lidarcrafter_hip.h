@@ -100,17 +100,25 @@ int lc_sinusoid_fwd(const float* t, float* y, int M, int channels, float max_per
  * nn.MultiheadAttention in SelfAttentionBlock efficient_unet.py:28-58;
  * QKVAttentionLegacy layout_unet_v1.py:555-596; ObjectAwareCrossAttention.forward
  * layout_unet_v1.py:489-506 (image keys ++ 13 layout keys, d_qk = 2*d_v).
- * Head (b,h) of operand X starts at X + b*X_bs + h*X_hs; channel stride X_cs.
- * Keys/values may come in two segments (k/v: Lk0 tokens, k2/v2: Lk1 tokens; pass NULL,0).
+ * An operand is described by lc_cm_operand: head (b,h) starts at p + b*bs + h*hs, channel
+ * stride cs, unit token stride.  The q/k channels of a head are the concatenation of a content
+ * part (dqk channels, operands q / k / k2) and an optional positional part (dpos channels,
+ * operands q_pos / k_pos / k2_pos; NULL when dpos == 0) -- the torch.cat([content, positional])
+ * of layout_unet_v1.py:453-454,476 is never materialised.  Keys/values come in two token
+ * segments: (k, k_pos, v) with Lk0 tokens and optionally (k2, k2_pos, v2) with Lk1 tokens
+ * (the 13 layout tokens, layout_unet_v1.py:479-480).  dqk+dpos <= 64, dv <= 64.
  * ------------------------------------------------------------------------------------------- */
-int lc_attention_fwd(const float* q, int64_t q_bs, int64_t q_hs, int64_t q_cs,
-                     const float* k, int64_t k_bs, int64_t k_hs, int64_t k_cs,
-                     const float* v, int64_t v_bs, int64_t v_hs, int64_t v_cs,
-                     const float* k2, int64_t k2_bs, int64_t k2_hs, int64_t k2_cs,
-                     const float* v2, int64_t v2_bs, int64_t v2_hs, int64_t v2_cs,
+typedef struct lc_cm_operand {
+    const float* p;
+    int64_t bs, hs, cs;
+} lc_cm_operand;
+
+int lc_attention_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
+                     const lc_cm_operand* k, const lc_cm_operand* k_pos, const lc_cm_operand* v,
+                     const lc_cm_operand* k2, const lc_cm_operand* k2_pos, const lc_cm_operand* v2,
                      float* o, int64_t o_bs, int64_t o_hs, int64_t o_cs,
-                     int B, int heads, int Lq, int Lk0, int Lk1, int dqk, int dv, float scale,
-                     lc_stream_t s);
+                     int B, int heads, int Lq, int Lk0, int Lk1, int dqk, int dpos, int dv,
+                     float scale, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse-diffusion update, one fused elementwise pass:

@@ -9,6 +9,14 @@ from .build import LIB
 
 i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 
+
+class CmOperand(C.Structure):
+    """struct lc_cm_operand: channel-major attention operand (pointer + batch/head/channel strides)."""
+    _fields_ = [("p", vp), ("bs", i64), ("hs", i64), ("cs", i64)]
+
+
+_op = C.POINTER(CmOperand)
+
 # name -> (restype, argtypes); mirrors include/lidarcrafter_hip.h one to one
 SIGNATURES = {
     "lc_abi_version": (i32, []),
@@ -24,9 +32,8 @@ SIGNATURES = {
     "lc_resample2x_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
     "lc_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "lc_sinusoid_fwd": (i32, [vp, vp, i32, i32, f32, vp]),
-    "lc_attention_fwd": (i32, [vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64,
-                               vp, i64, i64, i64, vp, i64, i64, i64, vp, i64, i64, i64,
-                               i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "lc_attention_fwd": (i32, [_op, _op, _op, _op, _op, _op, _op, _op, vp, i64, i64, i64,
+                               i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),
     "lc_add_scale": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, f32, vp]),

@@ -19,13 +19,16 @@
 namespace {
 
 struct AttnArgs {
-    const float *q, *k, *v, *k2, *v2;
+    lc_cm_operand q, qp, k, kp, v, k2, k2p, v2;
     float* o;
-    long long q_bs, q_hs, q_cs, k_bs, k_hs, k_cs, v_bs, v_hs, v_cs;
-    long long k2_bs, k2_hs, k2_cs, v2_bs, v2_hs, v2_cs, o_bs, o_hs, o_cs;
-    int heads, Lq, Lk0, Lk1, dqk, dv;
+    long long o_bs, o_hs, o_cs;
+    int heads, Lq, Lk0, Lk1, dqk, dpos, dv;
     float qscale;  // scale * log2(e)
 };
+
+__device__ __forceinline__ const float* head_ptr(const lc_cm_operand& x, int b, int h) {
+    return x.p ? x.p + b * x.bs + h * x.hs : nullptr;
+}
 
 template <int DQK, int NDV>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
@@ -40,12 +43,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int t = t0 + l31;
     const int Lk = a.Lk0 + a.Lk1;
 
-    const float* qp = a.q + b * a.q_bs + h * a.q_hs;
+    const int dq = a.dqk + a.dpos;  // channels of a head's q/k: content ++ positional
+    const float* qc = head_ptr(a.q, b, h);
+    const float* qpos = head_ptr(a.qp, b, h);
     float qreg[DQK / 2];
 #pragma unroll
     for (int kk = 0; kk < DQK / 2; ++kk) {
         const int c = 2 * kk + kh;
-        qreg[kk] = (c < a.dqk && t < a.Lq) ? qp[c * a.q_cs + t] * a.qscale : 0.f;
+        float val = 0.f;
+        if (t < a.Lq) {
+            if (c < a.dqk) val = qc[c * a.q.cs + t];
+            else if (c < dq) val = qpos[(c - a.dqk) * a.qp.cs + t];
+        }
+        qreg[kk] = val * a.qscale;
     }
     f32x16 oacc[NDV];
 #pragma unroll
@@ -54,10 +64,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const float* kp0 = a.k + b * a.k_bs + h * a.k_hs;
-    const float* vp0 = a.v + b * a.v_bs + h * a.v_hs;
-    const float* kp1 = a.k2 ? a.k2 + b * a.k2_bs + h * a.k2_hs : nullptr;
-    const float* vp1 = a.v2 ? a.v2 + b * a.v2_bs + h * a.v2_hs : nullptr;
+    const float* kc0 = head_ptr(a.k, b, h);
+    const float* kq0 = head_ptr(a.kp, b, h);
+    const float* vp0 = head_ptr(a.v, b, h);
+    const float* kc1 = head_ptr(a.k2, b, h);
+    const float* kq1 = head_ptr(a.k2p, b, h);
+    const float* vp1 = head_ptr(a.v2, b, h);
 
     for (int s0 = 0; s0 < Lk; s0 += 32) {
         __syncthreads();  // previous tile fully consumed
@@ -67,9 +79,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const int e = tid + i * 256;
             const int c = e >> 5, sl = e & 31, s = s0 + sl;
             float val = 0.f;
-            if (c < a.dqk) {
-                if (s < a.Lk0) val = kp0[c * a.k_cs + s];
-                else if (s < Lk) val = kp1[c * a.k2_cs + (s - a.Lk0)];
+            if (s < a.Lk0) {
+                if (c < a.dqk) val = kc0[c * a.k.cs + s];
+                else if (c < dq) val = kq0[(c - a.dqk) * a.kp.cs + s];
+            } else if (s < Lk) {
+                if (c < a.dqk) val = kc1[c * a.k2.cs + (s - a.Lk0)];
+                else if (c < dq) val = kq1[(c - a.dqk) * a.k2p.cs + (s - a.Lk0)];
             }
             ks[e] = val;
         }
@@ -79,8 +94,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const int c = e >> 5, sl = e & 31, s = s0 + sl;
             float val = 0.f;
             if (c < a.dv) {
-                if (s < a.Lk0) val = vp0[c * a.v_cs + s];
-                else if (s < Lk) val = vp1[c * a.v2_cs + (s - a.Lk0)];
+                if (s < a.Lk0) val = vp0[c * a.v.cs + s];
+                else if (s < Lk) val = vp1[c * a.v2.cs + (s - a.Lk0)];
             }
             vs[c * VS + sl] = val;
         }
@@ -144,27 +159,29 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int lc_attention_fwd(const float* q, int64_t q_bs, int64_t q_hs, int64_t q_cs,
-                                const float* k, int64_t k_bs, int64_t k_hs, int64_t k_cs,
-                                const float* v, int64_t v_bs, int64_t v_hs, int64_t v_cs,
-                                const float* k2, int64_t k2_bs, int64_t k2_hs, int64_t k2_cs,
-                                const float* v2, int64_t v2_bs, int64_t v2_hs, int64_t v2_cs,
-                                float* o, int64_t o_bs, int64_t o_hs, int64_t o_cs, int B, int heads,
-                                int Lq, int Lk0, int Lk1, int dqk, int dv, float scale,
+extern "C" int lc_attention_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
+                                const lc_cm_operand* k, const lc_cm_operand* k_pos,
+                                const lc_cm_operand* v, const lc_cm_operand* k2,
+                                const lc_cm_operand* k2_pos, const lc_cm_operand* v2, float* o,
+                                int64_t o_bs, int64_t o_hs, int64_t o_cs, int B, int heads, int Lq,
+                                int Lk0, int Lk1, int dqk, int dpos, int dv, float scale,
                                 lc_stream_t s) {
-    if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Lq <= 0 || Lk0 <= 0 || Lk1 < 0)
+    if (!q || !k || !v || !q->p || !k->p || !v->p || !o || B <= 0 || heads <= 0 || Lq <= 0 ||
+        Lk0 <= 0 || Lk1 < 0 || dpos < 0)
         return LC_EINVAL;
-    if (Lk1 > 0 && (!k2 || !v2)) return LC_EINVAL;
-    if (dqk <= 0 || dqk > 64 || dv <= 0 || dv > 64) return LC_EUNSUP;
+    if (Lk1 > 0 && (!k2 || !v2 || !k2->p || !v2->p)) return LC_EINVAL;
+    if (dpos > 0 && (!q_pos || !k_pos || !q_pos->p || !k_pos->p)) return LC_EINVAL;
+    if (dpos > 0 && Lk1 > 0 && (!k2_pos || !k2_pos->p)) return LC_EINVAL;
+    if (dqk <= 0 || dqk + dpos > 64 || dv <= 0 || dv > 64) return LC_EUNSUP;
+    const lc_cm_operand none = {nullptr, 0, 0, 0};
     AttnArgs a;
-    a.q = q; a.k = k; a.v = v; a.k2 = k2; a.v2 = v2; a.o = o;
-    a.q_bs = q_bs; a.q_hs = q_hs; a.q_cs = q_cs; a.k_bs = k_bs; a.k_hs = k_hs; a.k_cs = k_cs;
-    a.v_bs = v_bs; a.v_hs = v_hs; a.v_cs = v_cs; a.k2_bs = k2_bs; a.k2_hs = k2_hs; a.k2_cs = k2_cs;
-    a.v2_bs = v2_bs; a.v2_hs = v2_hs; a.v2_cs = v2_cs; a.o_bs = o_bs; a.o_hs = o_hs; a.o_cs = o_cs;
-    a.heads = heads; a.Lq = Lq; a.Lk0 = Lk0; a.Lk1 = Lk1; a.dqk = dqk; a.dv = dv;
+    a.q = *q; a.qp = q_pos ? *q_pos : none; a.k = *k; a.kp = k_pos ? *k_pos : none; a.v = *v;
+    a.k2 = k2 ? *k2 : none; a.k2p = k2_pos ? *k2_pos : none; a.v2 = v2 ? *v2 : none;
+    a.o = o; a.o_bs = o_bs; a.o_hs = o_hs; a.o_cs = o_cs;
+    a.heads = heads; a.Lq = Lq; a.Lk0 = Lk0; a.Lk1 = Lk1; a.dqk = dqk; a.dpos = dpos; a.dv = dv;
     a.qscale = scale * 1.4426950408889634f;
     dim3 grid((Lq + 127) / 128, B * heads);
-    const int dq = dqk <= 32 ? 32 : 64, nd = dv <= 32 ? 1 : 2;
+    const int dq = (dqk + dpos) <= 32 ? 32 : 64, nd = dv <= 32 ? 1 : 2;
     if (dq == 32 && nd == 1) hipLaunchKernelGGL((attn_kernel<32, 1>), grid, dim3(256), 0, lc_s(s), a);
     else if (dq == 64 && nd == 1) hipLaunchKernelGGL((attn_kernel<64, 1>), grid, dim3(256), 0, lc_s(s), a);
     else if (dq == 32 && nd == 2) hipLaunchKernelGGL((attn_kernel<32, 2>), grid, dim3(256), 0, lc_s(s), a);

@@ -125,7 +125,7 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         return K.pstep(x_t, pred, noise, coef.to(x_t.device), self._objective_id(),
                        schedules.MODES[mode])
 
-    def _plan(self, batch_size, num_steps, mode, ddim_eta, device):
+    def _plan(self, batch_size, num_steps, mode, ddim_eta, device, other_condition=None):
         """Host-side tables for a whole run: log-SNR rows [S*B] and coefficients [S,B,8]."""
         if mode not in schedules.MODES:
             raise ValueError(f"invalid mode {mode}")
@@ -136,7 +136,10 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         lam_rows = lam[:-1, None].expand(num_steps, batch_size).contiguous().to(device)
         tf_all = None
         if hasattr(self.model, "time_features"):
-            tf_all = self.model.time_features(lam_rows.reshape(-1))
+            if isinstance(other_condition, dict):
+                tf_all = self.model.time_features(lam_rows.reshape(-1), other_condition)
+            elif other_condition is None:
+                tf_all = self.model.time_features(lam_rows.reshape(-1))
         return lam_rows, coef, tf_all
 
     def _resident_x(self, x):
@@ -149,14 +152,20 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     # ---- the sampling loop, exposed step-wise (bench.py times exactly K calls of `sampling_step`)
     @torch.inference_mode()
     def begin_sampling(self, batch_size: int, num_steps: int, rng=None,
-                       mode: Literal["ddpm", "ddim"] = "ddpm", ddim_eta: float = 0.0, x_T=None):
+                       mode: Literal["ddpm", "ddim"] = "ddpm", ddim_eta: float = 0.0, x_T=None,
+                       condition_dict: dict = None):
         """Draw x_T (or take it), build the per-run tables, make x resident.  Returns a state dict
         consumed by `sampling_step`."""
         x = x_T if x_T is not None else self.randn(batch_size, *self.sampling_shape, rng=rng,
                                                    device=self.device)
         x0 = x.clone()
-        lam_rows, coef, tf_all = self._plan(batch_size, num_steps, mode, ddim_eta, self.device)
+        other = None if condition_dict is None else condition_dict["other_condition"]
+        lam_rows, coef, tf_all = self._plan(batch_size, num_steps, mode, ddim_eta, self.device,
+                                            other)
+        if isinstance(other, dict) and hasattr(self.model, "prepare_condition"):
+            self.model.prepare_condition(other)   # step-invariant attention operands, once
         return dict(x=self._resident_x(x), x_T=x0, i=0, n=num_steps, B=batch_size, rng=rng,
+                    cond=condition_dict,
                     mode=mode, eta=ddim_eta, lam=lam_rows, coef=coef, tf=tf_all,
                     obj=self._objective_id(), mid=schedules.MODES[mode])
 
@@ -165,7 +174,11 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         """One reverse step: denoiser forward + fused x0/clamp/update, in place on the resident x."""
         i, B, x = st["i"], st["B"], st["x"]
         tf = None if st["tf"] is None else tuple(a[i * B:(i + 1) * B] for a in st["tf"])
-        pred = self._predict(x, st["lam"][i], tf)
+        if st["cond"] is not None:
+            st["cond"].update(dict(time_condition=st["lam"][i]))  # mutates, like the reference
+            pred = self._predict_cond(x, st["cond"], tf)
+        else:
+            pred = self._predict(x, st["lam"][i], tf)
         noise = self._noise_for(x, st["rng"], st["mode"], st["eta"])
         K.pstep(x, pred, noise, st["coef"][i], st["obj"], st["mid"], out=x)
         st["i"] = i + 1

@@ -58,24 +58,17 @@ class CondContinuousTimeGaussianDiffusion(continuous_time.ContinuousTimeGaussian
     def sample(self, batch_dict: dict, batch_size: int, num_steps: int, progress: bool = True,
                rng=None, return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
-        x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
+        x_T = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
         condition_dict = self.get_network_condition(input_dict=batch_dict,
                                                     only_custom_condition=True)
-        out = [x.clone()] if return_all else None
-        lam_rows, coef, tf_all = self._plan(batch_size, num_steps, mode, ddim_eta, self.device)
-        if hasattr(self.model, "prepare_condition"):
-            self.model.prepare_condition(condition_dict["other_condition"])  # step-invariant parts
-        x = self._resident_x(x)
-        B, obj, mid = batch_size, self._objective_id(), schedules.MODES[mode]
-        for i in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-            tf = None if tf_all is None else tuple(a[i * B:(i + 1) * B] for a in tf_all)
-            condition_dict.update(dict(time_condition=lam_rows[i]))
-            pred = self._predict_cond(x, condition_dict, tf)
-            noise = self._noise_for(x, rng, mode, ddim_eta)
-            K.pstep(x, pred, noise, coef[i], obj, mid, out=x)
+        st = self.begin_sampling(batch_size, num_steps, rng, mode, ddim_eta, x_T=x_T,
+                                 condition_dict=condition_dict)
+        out = [st["x_T"]] if return_all else None
+        for _ in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+            x = self.sampling_step(st)
             if return_all:
                 out.append(x.clone())
-        return torch.stack(out) if return_all else x.clone()
+        return torch.stack(out) if return_all else st["x"].clone()
 
     @torch.inference_mode()
     def inpaint(self, known, mask, batch_dict: dict, num_steps: int, num_resample_steps: int = 1,

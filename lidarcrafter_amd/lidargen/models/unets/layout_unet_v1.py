@@ -1,0 +1,361 @@
+"""Layout-conditioned range-image denoiser (LayoutUnetV1) on the gfx950 kernels.
+
+API / state_dict mirror of the reference's lidargen/models/unets/layout_unet_v1.py
+(TimestepEmbedSequential :63-78, ResBlock :143-249, ObjectAwareCrossAttention :347-532,
+LayoutUnetV1 :599-902) for the configuration every shipped layout config uses
+(`ObjectAwareCrossAttention`, `use_scale_shift_norm`, `resblock_updown`, fp32), restructured:
+
+  * joint image/layout attention never materialises the [B*heads, L1, L1+13] score tensor nor the
+    torch.cat of content|positional channels or image|layout keys: one flash-style launch
+    (lc_attention_fwd) takes the parts as separate operands;
+  * everything that depends only on the layout condition (positional embeddings of image patches
+    and objects, layout keys/values of all 11 attention blocks) is computed once per batch in
+    `prepare_condition`, not once per step as in the reference;
+  * emb_layers of all ResBlocks are one dense launch; skip concatenations are free (producers
+    write into slices of pre-concatenated buffers); GN->SiLU fused; skip + h in the conv epilogue.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch as th
+import torch.nn as nn
+
+from lidarcrafter_amd import ops as K
+
+from . import encoding, ops
+from .nn import SiLU, conv_nd, conv_nd_range, linear, normalization, zero_module
+
+
+class TimestepBlock(nn.Module):
+    """Any module whose forward takes the timestep embedding as a second argument."""
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if not use_scale_shift_norm or dims != 2:
+            raise NotImplementedError("HIP ResBlock: use_scale_shift_norm=True, dims=2 "
+                                      "(all shipped layout configs)")
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_scale_shift_norm = True
+        self.in_layers = nn.Sequential(
+            normalization(channels), SiLU(),
+            conv_nd_range(dims, channels, self.out_channels, 3, padding=1, ring=True))
+        self.updown = up or down
+        if up:
+            self.op = ops.Resample(up=2, ring=True)
+        elif down:
+            self.op = ops.Resample(down=2, ring=True)
+        else:
+            self.op = nn.Identity()
+        self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, 2 * self.out_channels))
+        self.out_layers = nn.Sequential(
+            normalization(self.out_channels), SiLU(), nn.Dropout(p=dropout),
+            zero_module(conv_nd_range(dims, self.out_channels, self.out_channels, 3, padding=1,
+                                      ring=True)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd_range(dims, channels, self.out_channels, 3, padding=1,
+                                                 ring=True)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def scale_shift(self, emb):
+        ss = K.linear(emb, self.emb_layers[1].weight, self.emb_layers[1].bias, act_in=True)
+        C = self.out_channels
+        return ss[:, :C], ss[:, C:]
+
+    def forward(self, x, emb=None, scale_shift=None, out=None):
+        a = self.in_layers[0](x, act_silu=True)
+        if self.updown:
+            a, x = self.op(a), self.op(x)
+        h = self.in_layers[2](a)
+        scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
+        a2 = self.out_layers[0](h, scale, shift, act_silu=True,
+                                out=a if a.shape == h.shape else None)
+        sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
+        return self.out_layers[3](a2, res=sk, out=out)
+
+
+class ObjectAwareCrossAttention(nn.Module):
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False,
+                 encoder_channels=None, return_attention_embeddings=False, ds=None,
+                 resolution=None, type=None, use_positional_embedding=True,
+                 use_key_padding_mask=False, channels_scale_for_positional_embedding=1.0,
+                 norm_first=False, norm_for_obj_embedding=False):
+        super().__init__()
+        if norm_first or norm_for_obj_embedding or use_key_padding_mask or \
+                channels_scale_for_positional_embedding != 1.0 or return_attention_embeddings:
+            raise NotImplementedError("HIP ObjectAwareCrossAttention implements the shipped "
+                                      "configuration (norm_first=False, no key padding mask)")
+        assert use_positional_embedding and encoder_channels is not None
+        self.type, self.ds, self.resolution, self.channels = type, ds, resolution, channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0
+            self.num_heads = channels // num_head_channels
+        self.encoder_channels = encoder_channels
+        self.qkv_projector = conv_nd(1, channels, 3 * channels, 1)
+        self.norm_for_qkv = normalization(channels)
+        self.layout_content_embedding_projector = conv_nd(1, encoder_channels, channels * 2, 1)
+        self.layout_position_embedding_projector = conv_nd(1, encoder_channels, channels, 1)
+        self.norm_for_obj_class_embedding = normalization(encoder_channels)
+        self.norm_for_layout_positional_embedding = normalization(channels)
+        self.norm_for_image_patch_positional_embedding = normalization(channels)
+        self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
+        self._cond_cache = None
+
+    def condition_operands(self, cond):
+        """Step-invariant operands (reference recomputes them every step, :431-476)."""
+        img = cond[f"image_patch_bbox_embedding_for_resolution{self.resolution}"]
+        key = (img.data_ptr(), cond["obj_bbox_embedding"].data_ptr(), cond["xf_out"].data_ptr(),
+               cond["obj_class_embedding"].data_ptr(), _ver(cond["xf_out"]),
+               self.layout_position_embedding_projector.weight._version,
+               self.layout_content_embedding_projector.weight._version)
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            C = self.channels
+            pos_img = self.norm_for_image_patch_positional_embedding(
+                self.layout_position_embedding_projector(img))
+            pos_lay = self.norm_for_layout_positional_embedding(
+                self.layout_position_embedding_projector(cond["obj_bbox_embedding"]))
+            cls = self.norm_for_obj_class_embedding(cond["obj_class_embedding"])
+            B, E, L2 = cls.shape
+            content = K.add_scale(cond["xf_out"].reshape(B, E, 1, L2), cls.view(B, E, 1, L2), 0.5)
+            kv = self.layout_content_embedding_projector(content.view(B, E, L2))
+            self._cond_cache = (key, pos_img, pos_lay, kv[:, :C], kv[:, C:])
+        return self._cond_cache[1:]
+
+    def forward(self, x, cond_kwargs, out=None):
+        B, C, H, W = x.shape
+        L1 = H * W
+        xs = x.reshape(B, C, L1) if x.is_contiguous() else x.contiguous().view(B, C, L1)
+        pos_img, pos_lay, k_lay, v_lay = self.condition_operands(cond_kwargs)
+        qkv = self.qkv_projector(self.norm_for_qkv(xs))
+        heads = self.num_heads
+        scale = 1.0 / math.sqrt(2 * C // heads)   # (q*s)(k*s) with s = (2C/h)^-1/4, :489-492
+        a = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale,
+                           k2=k_lay, v2=v_lay, q_pos=pos_img, k_pos=pos_img, k2_pos=pos_lay)
+        o3 = None if out is None else out
+        y = self.proj_out(a, res=xs, out=None if o3 is None else _as3(o3))
+        return (y.view(B, C, H, W) if out is None else out), None
+
+
+def _ver(t):
+    """Version counter of a tensor (inference-mode tensors do not track one)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
+def _as3(t4):
+    B, C, H, W = t4.shape
+    return torch.as_strided(t4, (B, C, H * W), (t4.stride(0), t4.stride(1), 1))
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    def forward(self, x, emb, cond_kwargs=None, scale_shifts=None, out=None):
+        """`scale_shifts`: iterator of precomputed (scale, shift) pairs for the ResBlocks inside;
+        `out`: destination view for the LAST layer's result."""
+        n = len(self)
+        for i, layer in enumerate(self):
+            o = out if i == n - 1 else None
+            if isinstance(layer, ResBlock):
+                ss = next(scale_shifts) if scale_shifts is not None else None
+                x = layer(x, emb, scale_shift=ss, out=o)
+            elif isinstance(layer, ObjectAwareCrossAttention):
+                x, _ = layer(x, cond_kwargs, out=o)
+            else:
+                x = layer(x, out=o)
+        return x, None
+
+
+class LayoutUnetV1(nn.Module):
+    def __init__(self, in_channels, resolution, model_channels, out_channels, num_res_blocks,
+                 attention_ds, encoder_channels=None, dropout=0, channel_mult=(1, 2, 4, 8),
+                 conv_resample=True, dims=2, use_checkpoint=False, use_fp16=False, num_heads=1,
+                 num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_positional_embedding_for_attention=False,
+                 image_size=256, attention_block_type="GLIDE", num_attention_blocks=1,
+                 use_key_padding_mask=False, channels_scale_for_positional_embedding=1.0,
+                 norm_first=False, norm_for_obj_embedding=False,
+                 coords_encoding="fourier_features", **kwargs):
+        super().__init__()
+        if attention_block_type != "ObjectAwareCrossAttention" or not resblock_updown or use_fp16 \
+                or coords_encoding != "fourier_features":
+            raise NotImplementedError(
+                "HIP LayoutUnetV1 implements the shipped configuration: ObjectAwareCrossAttention, "
+                "resblock_updown, fourier_features, fp32 (option_nusc_box_layout_v6.py:10-32)")
+        self.in_channels = in_channels
+        self.image_size = image_size
+        self.resolution = tuple(resolution)
+        self.register_buffer("coords", encoding.generate_polar_coords(*self.resolution))
+        self.coords_encoding = encoding.FourierFeatures(self.resolution)
+        cin = in_channels + self.coords_encoding.extra_ch
+        self.encoder_channels, self.model_channels = encoder_channels, model_channels
+        self.out_channels, self.num_res_blocks = out_channels, num_res_blocks
+        self.attention_ds, self.dropout, self.channel_mult = attention_ds, dropout, channel_mult
+        self.dtype = th.float32
+        self.num_heads, self.num_head_channels = num_heads, num_head_channels
+        self.num_heads_upsample = num_heads if num_heads_upsample == -1 else num_heads_upsample
+        self.num_attention_blocks = num_attention_blocks
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(ops.SinusoidalPositionalEmbedding(model_channels),
+                                        nn.Linear(model_channels, ted), nn.SiLU(),
+                                        nn.Linear(ted, ted))
+
+        def res(ch_in, ch_out=None, **kw):
+            return ResBlock(ch_in, ted, dropout, out_channels=ch_out, dims=dims,
+                            use_scale_shift_norm=use_scale_shift_norm, **kw)
+
+        def attn(ch, ds, kind, heads):
+            return ObjectAwareCrossAttention(
+                ch, num_heads=heads, num_head_channels=num_head_channels,
+                encoder_channels=encoder_channels, ds=ds, resolution=int(image_size // ds),
+                type=kind, use_positional_embedding=use_positional_embedding_for_attention,
+                use_key_padding_mask=use_key_padding_mask,
+                channels_scale_for_positional_embedding=channels_scale_for_positional_embedding,
+                norm_first=norm_first, norm_for_obj_embedding=norm_for_obj_embedding)
+
+        ch = input_ch = int(channel_mult[0] * model_channels)
+        self.input_blocks = nn.ModuleList(
+            [TimestepEmbedSequential(conv_nd_range(dims, cin, ch, 3, padding=1, ring=True))])
+        chans, dss, ds = [ch], [1], 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, int(mult * model_channels))]
+                ch = int(mult * model_channels)
+                if ds in attention_ds:
+                    layers += [attn(ch, ds, "input", num_heads) for _ in range(num_attention_blocks)]
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch), dss.append(ds)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(res(ch, ch, down=True)))
+                ds *= 2
+                chans.append(ch), dss.append(ds)
+        self.middle_block = TimestepEmbedSequential(res(ch), attn(ch, ds, "middle", num_heads),
+                                                    res(ch))
+        self._skip_chans, self._skip_ds = list(chans), list(dss)
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [res(ch + ich, int(model_channels * mult))]
+                ch = int(model_channels * mult)
+                if ds in attention_ds:
+                    layers += [attn(ch, ds, "output", self.num_heads_upsample)
+                               for _ in range(num_attention_blocks)]
+                if level and i == num_res_blocks:
+                    layers.append(res(ch, ch, up=True))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), SiLU(),
+                                 zero_module(conv_nd_range(dims, input_ch, out_channels, 3,
+                                                           padding=1, ring=True)))
+        self.use_fp16 = use_fp16
+        self._emb_cache = None
+        self._in_buf = None
+
+    # ---- batched / step-invariant helpers -------------------------------------------------------
+    def _res_blocks(self):
+        seqs = list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
+        return [m for s in seqs for m in s if isinstance(m, ResBlock)]
+
+    def _emb_weights(self):
+        mods = self._res_blocks()
+        key = tuple((m.emb_layers[1].weight.data_ptr(), m.emb_layers[1].weight._version,
+                     m.emb_layers[1].bias._version) for m in mods)
+        if self._emb_cache is None or self._emb_cache[0] != key:
+            w = torch.cat([m.emb_layers[1].weight.detach() for m in mods], 0).contiguous()
+            b = torch.cat([m.emb_layers[1].bias.detach() for m in mods], 0).contiguous()
+            self._emb_cache = (key, w, b)
+        return self._emb_cache[1], self._emb_cache[2]
+
+    def time_features(self, log_snr: torch.Tensor, other_condition: dict = None):
+        """log-SNR [M] (M = S*B rows, step-major) + xf_proj [B, T] ->
+        (emb [M, T], all ResBlock (scale|shift) rows [M, sum 2C])."""
+        te = self.time_embed
+        h = K.linear(te[0](log_snr), te[1].weight, te[1].bias, act_out=True)
+        emb = K.linear(h, te[3].weight, te[3].bias)
+        if other_condition is not None:
+            xf = other_condition["xf_proj"].to(emb)
+            emb = (emb.view(-1, xf.shape[0], emb.shape[1]) + xf[None]).view(emb.shape)
+        w, b = self._emb_weights()
+        return emb, K.linear(emb, w, b, act_in=True)
+
+    def _ss_iter(self, ss):
+        off = 0
+        for m in self._res_blocks():
+            C = m.out_channels
+            yield ss[:, off:off + C], ss[:, off + C:off + 2 * C]
+            off += 2 * C
+
+    def _input_buffer(self, B, x):
+        """Persistent [B, in_channels + 30, H, W] buffer: x | concat_cond | Fourier features."""
+        H, W = self.resolution
+        enc = self.coords_encoding(self.coords)
+        key = (B, x.device, enc.data_ptr())
+        if self._in_buf is None or self._in_buf[0] != key:
+            buf = torch.empty((B, self.in_channels + enc.shape[1], H, W), device=x.device,
+                              dtype=torch.float32)
+            K.copy_into(buf[:, self.in_channels:], enc.expand(B, -1, -1, -1) if B > 1 else enc)
+            self._in_buf = (key, buf, None)
+        return self._in_buf[1]
+
+    def prepare_condition(self, layout_outputs: dict):
+        """Compute everything that depends only on the layout condition (once per batch)."""
+        seqs = list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
+        for s in seqs:
+            for m in s:
+                if isinstance(m, ObjectAwareCrossAttention):
+                    m.condition_operands(layout_outputs)
+
+    def forward(self, x, cond_dict, time_features=None):
+        lay = cond_dict["other_condition"]
+        B, cx, H, W = x.shape
+        if time_features is None:
+            t = cond_dict["time_condition"]
+            if t.dim() == 0:
+                t = t[None].repeat_interleave(B, dim=0)
+            time_features = self.time_features(t.to(x), lay)
+        emb, ss = time_features
+        ssi = self._ss_iter(ss)
+        buf = self._input_buffer(B, x)
+        if x.data_ptr() != buf.data_ptr():
+            K.copy_into(buf[:, :cx], x)
+        if "concat_cond" in lay:
+            cc = lay["concat_cond"]
+            ck = (cc.data_ptr(), _ver(cc))
+            if self._in_buf[2] != ck:   # condition channels are step-invariant: copy once
+                K.copy_into(buf[:, cx:cx + cc.shape[1]], cc.float().contiguous())
+                self._in_buf = (self._in_buf[0], buf, ck)
+        dev = x.device
+        # pre-concatenated buffers: output block j reads cat[h, skip_(n-1-j)]
+        n_in = len(self.input_blocks)
+        first = [next(m for m in blk if isinstance(m, ResBlock)).channels for blk in self.output_blocks]
+        cats = []
+        for j in range(len(self.output_blocks)):
+            i = n_in - 1 - j
+            d = self._skip_ds[i]
+            cats.append(torch.empty((B, first[j], H // d, W // d), device=dev, dtype=torch.float32))
+        h = buf
+        for i, blk in enumerate(self.input_blocks):
+            j = n_in - 1 - i
+            dst = cats[j][:, first[j] - self._skip_chans[i]:]
+            h, _ = blk(h, emb, lay, scale_shifts=ssi, out=dst)
+        dst = cats[0][:, : first[0] - self._skip_chans[n_in - 1]]
+        self.middle_block(h, emb, lay, scale_shifts=ssi, out=dst)
+        for j, blk in enumerate(self.output_blocks):
+            if j + 1 < len(self.output_blocks):
+                dst = cats[j + 1][:, : first[j + 1] - self._skip_chans[n_in - 2 - j]]
+            else:
+                dst = None
+            h, _ = blk(cats[j], emb, lay, scale_shifts=ssi, out=dst)
+        a = self.out[0](h, act_silu=True)
+        return self.out[2](a)

@@ -1,0 +1,77 @@
+"""Small helpers of the guided-diffusion style UNet -- API mirror of the reference's
+lidargen/models/unets/nn.py (GroupNorm32 :17-19, conv_nd :22-31, conv_nd_range :34-44,
+linear :46-50, zero_module :79-85, normalization :104-111), HIP-backed where they compute."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from lidarcrafter_amd import ops as K
+
+from . import ops
+
+
+class SiLU(nn.Module):
+    """Marker only: SiLU is fused into the preceding GroupNorm kernel on this path."""
+
+    def forward(self, x):
+        raise RuntimeError("SiLU is fused into lc_groupnorm_apply; never run on its own")
+
+
+class GroupNorm32(nn.GroupNorm):
+    """fp32 GroupNorm on [B,C,H,W] or [B,C,L] (+ optional scale/shift, + optional SiLU)."""
+
+    def forward(self, x, scale=None, shift=None, act_silu: bool = False, out=None):
+        if x.dim() == 3:
+            B, C, L = x.shape
+            o4 = None if out is None else out.view(B, C, 1, L)
+            y = K.groupnorm(x.reshape(B, C, 1, L), self.num_groups, self.eps, self.weight,
+                            self.bias, scale, shift, act_silu=act_silu, out=o4)
+            return y.view(B, C, L)
+        return K.groupnorm(x, self.num_groups, self.eps, self.weight, self.bias, scale, shift,
+                           act_silu=act_silu, out=out)
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1) parameters ([Co, Ci, 1]) driven through the 1x1 MFMA conv."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1):
+        assert kernel_size == 1
+        super().__init__(in_channels, out_channels, 1)
+        self._packed = K.PackedConv()
+
+    def forward(self, x, res=None, out=None):
+        B, C, L = x.shape
+        r4 = None if res is None else res.reshape(B, -1, 1, L)
+        o4 = None if out is None else out.view(B, -1, 1, L)
+        y = K.conv2d_ring(x.reshape(B, C, 1, L), self._packed, self.weight, self.bias, res=r4,
+                          out=o4)
+        return y.view(B, -1, L)
+
+
+def conv_nd(dims, *args, **kwargs):
+    if dims == 1:
+        return PointwiseConv1d(*args, **kwargs)
+    if dims == 2:
+        kwargs.setdefault("padding", 0)
+        return ops.Conv2d(*args, **kwargs)
+    raise ValueError(f"unsupported dimensions: {dims}")
+
+
+def conv_nd_range(dims, *args, **kwargs):
+    if dims == 2:
+        return ops.Conv2d(*args, **kwargs)
+    return conv_nd(dims, *args, **kwargs)
+
+
+def linear(*args, **kwargs):
+    return nn.Linear(*args, **kwargs)
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def normalization(channels):
+    return GroupNorm32(32, channels)

@@ -215,35 +215,44 @@ def sinusoid(t: torch.Tensor, channels: int, max_period: float = 10_000.0) -> to
 
 
 # ------------------------------------------------------------------------------------ attention
-def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None, q_pos=None, k_pos=None,
+                 k2_pos=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Channel-major attention.  q:[B, heads*dqk, Lq]  k:[B, heads*dqk, Lk0]  v:[B, heads*dv, Lk0]
-    (views with arbitrary batch/channel strides, unit token stride); optional second key/value
-    segment k2/v2 with Lk1 tokens (the 13 layout tokens of ObjectAwareCrossAttention)."""
-    for n_, t_ in (("q", q), ("k", k), ("v", v)):
+    (views with arbitrary batch/channel strides, unit token stride).  Optional positional parts
+    q_pos/k_pos/k2_pos [B, heads*dpos, L] are concatenated to each head's q/k channels inside the
+    kernel; optional second key/value segment k2/v2 with Lk1 tokens (the 13 layout tokens of
+    ObjectAwareCrossAttention).  Batch stride 0 (expand) is allowed for step-invariant operands."""
+    from ._lib import CmOperand
+    import ctypes as C
+
+    def chk(n_, t_):
         _req(t_, n_)
-        if t_.dim() != 3 or t_.stride(2) != 1:
+        if t_.dim() != 3 or (t_.shape[2] > 1 and t_.stride(2) != 1):
             raise ValueError(f"attention: `{n_}` must be [B,C,L] with unit token stride")
+
+    for n_, t_ in (("q", q), ("k", k), ("v", v)):
+        chk(n_, t_)
     B, Cq, Lq = q.shape
     dqk, dv = Cq // heads, v.shape[1] // heads
     Lk0 = k.shape[2]
-    Lk1 = 0
-    if k2 is not None:
-        _req(k2, "k2"), _req(v2, "v2")
-        Lk1 = k2.shape[2]
+    Lk1 = 0 if k2 is None else k2.shape[2]
+    dpos = 0 if q_pos is None else q_pos.shape[1] // heads
     if out is None:
         out = torch.empty((B, heads * dv, Lq), device=q.device, dtype=_F32)
 
-    def st(t, d):
-        return (t.stride(0), d * t.stride(1), t.stride(1))
+    def op(t, d):
+        if t is None:
+            return None
+        chk("operand", t)
+        return C.byref(CmOperand(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else 0,
+                                 d * t.stride(1), t.stride(1)))
 
-    z = (0, 0, 0)
-    args = [q.data_ptr(), *st(q, dqk), k.data_ptr(), *st(k, dqk), v.data_ptr(), *st(v, dv),
-            _p(k2), *(st(k2, dqk) if k2 is not None else z),
-            _p(v2), *(st(v2, dv) if v2 is not None else z),
-            out.data_ptr(), *st(out, dv), B, heads, Lq, Lk0, Lk1, dqk, dv, float(scale), _stream()]
-    with _Timed("attention", 2.0 * B * heads * Lq * (Lk0 + Lk1) * (dqk + dv)):
-        check(lib().lc_attention_fwd(*args), "lc_attention_fwd")
+    with _Timed("attention", 2.0 * B * heads * Lq * (Lk0 + Lk1) * (dqk + dpos + dv)):
+        check(lib().lc_attention_fwd(op(q, dqk), op(q_pos, dpos), op(k, dqk), op(k_pos, dpos),
+                                     op(v, dv), op(k2, dqk), op(k2_pos, dpos), op(v2, dv),
+                                     out.data_ptr(), out.stride(0), dv * out.stride(1),
+                                     out.stride(1), B, heads, Lq, Lk0, Lk1, dqk, dpos, dv,
+                                     float(scale), _stream()), "lc_attention_fwd")
     return out
 
 

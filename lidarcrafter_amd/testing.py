@@ -60,3 +60,45 @@ def synth_points(N: int, seed: int):
     r = np.exp(g.uniform(np.log(0.8), np.log(95.0), N))
     return np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el),
                      g.uniform(0, 255, N)], axis=1).astype(np.float32)
+
+
+def synth_layout_batch(B: int, H: int, W: int, seed: int, n_extra: int = 0) -> dict:
+    """Synthetic layout-condition batch: 13 object slots,
+    n_valid ~ U{1..12}; scaled 3-D boxes U(-1,1) with class id U{1..8} in the last column (0 for
+    padding); sorted 2-D corners U(0,1); `concat_cond` [B,10,H,W] = one-hot(9) of a rasterised
+    class map + one log-depth channel (the output of `preprocess_condition_mask`,
+    tools/evaluation/sample_and_save_cond.py:106-117).  n_extra>0 adds `autoregressive_cond`."""
+    import numpy as np
+
+    g = np.random.default_rng(seed)
+    boxes = np.zeros((B, 13, 9), np.float32)
+    b2d = np.zeros((B, 13, 4), np.float32)
+    valid = np.zeros((B, 13), np.float32)
+    cls_map = np.zeros((B, H, W), np.int64)
+    dep_map = np.zeros((B, H, W), np.float32)
+    for b in range(B):
+        n = int(g.integers(1, 13))
+        valid[b, :n] = 1
+        boxes[b, :n, :8] = g.uniform(-1, 1, (n, 8))
+        boxes[b, :n, 8] = g.integers(1, 9, n)
+        xs = np.sort(g.uniform(0, 1, (n, 2)), axis=1)
+        ys = np.sort(g.uniform(0, 1, (n, 2)), axis=1)
+        b2d[b, :n] = np.stack([xs[:, 0], ys[:, 0], xs[:, 1], ys[:, 1]], 1)
+        for k in range(n):
+            x0, x1 = int(xs[k, 0] * W), max(int(xs[k, 1] * W), int(xs[k, 0] * W) + 1)
+            y0, y1 = int(ys[k, 0] * H), max(int(ys[k, 1] * H), int(ys[k, 0] * H) + 1)
+            cls_map[b, y0:y1, x0:x1] = int(boxes[b, k, 8])
+            dep_map[b, y0:y1, x0:x1] = g.uniform(2, 60)
+    onehot = np.eye(9, dtype=np.float32)[cls_map].transpose(0, 3, 1, 2)
+    logd = np.clip(np.log2(dep_map + 1) / np.log2(81.0), 0, 1) * ((dep_map > 1.45) & (dep_map < 80))
+    out = {
+        "scaled_gt_boxes": torch.from_numpy(boxes),
+        "gt_boxes_2d": torch.from_numpy(b2d),
+        "is_valid_obj": torch.from_numpy(valid),
+        "concat_cond": torch.from_numpy(np.ascontiguousarray(
+            np.concatenate([onehot, logd[:, None].astype(np.float32)], 1))),
+    }
+    if n_extra:
+        out["autoregressive_cond"] = torch.from_numpy(
+            g.uniform(0, 1, (B, n_extra, H, W)).astype(np.float32))
+    return out

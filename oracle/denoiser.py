@@ -183,3 +183,166 @@ def efficient_unet_forward(sd, x, log_snr, *, gn_num_groups=8, gn_eps=1e-6, attn
     h = unet_block(sd, p + "u_block2", torch.cat([h, h2], 1), temb, G, eps, nh)
     h = unet_block(sd, p + "u_block1", torch.cat([h, h1], 1), temb, G, eps, nh)
     return conv_sd(sd, p + "out_conv", h)
+
+
+# ----------------------------------------------------------------------------- layout-conditioned
+# Restates /root/reference/lidargen/models/unets/layout_encoder.py:61-137 (Transformer),
+# :237-303 (LayoutTransformerEncoder.forward) and layout_unet_v1.py:143-249 (ResBlock),
+# :347-532 (ObjectAwareCrossAttention), :866-902 (LayoutUnetV1.forward); nn.py:17-19 GroupNorm32.
+def gn32(sd, pre, x):
+    return F.group_norm(x.float(), 32, sd[pre + ".weight"], sd[pre + ".bias"], 1e-5)
+
+
+def _ln(sd, pre, x):
+    return F.layer_norm(x, x.shape[-1:], sd[pre + ".weight"], sd[pre + ".bias"], 1e-5)
+
+
+def _xf_attention(qkv, heads):
+    B, T, width = qkv.shape
+    ch = width // heads // 3
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    q, k, v = qkv.view(B, T, heads, -1).split(ch, dim=-1)
+    w = torch.einsum("bthc,bshc->bhts", q * scale, k * scale).softmax(-1)
+    return torch.einsum("bhts,bshc->bthc", w, v).reshape(B, T, -1)
+
+
+@torch.no_grad()
+def layout_encoder_forward(sd, batch, *, feature_map_size, resolution_to_attention, num_heads=4,
+                           prefix=""):
+    """-> the condition dict the denoiser consumes (layout_encoder.py:237-303, configuration
+    used_condition_types=[obj_class,obj_bbox,is_valid_obj], no positional embedding, final LN)."""
+    p = prefix
+    boxes = batch["scaled_gt_boxes"]
+    cls_emb = F.embedding(boxes[..., -1].long(), sd[p + "obj_class_embedding.weight"])
+    box3 = F.linear(boxes[..., :8].float(), sd[p + "obj_bbox_embedding.weight"],
+                    sd[p + "obj_bbox_embedding.bias"])
+    box2 = F.linear(batch["gt_boxes_2d"].float(), sd[p + "obj_bbox_2d_embedding.weight"],
+                    sd[p + "obj_bbox_2d_embedding.bias"])
+    out = {"obj_class_embedding": cls_emb.permute(0, 2, 1),
+           "obj_bbox_embedding": box2.permute(0, 2, 1)}
+    B = boxes.shape[0]
+    for r in resolution_to_attention:
+        nh, nw = int(feature_map_size[0] / r), int(feature_map_size[1] / r)
+        di, dj = 1.0 / (feature_map_size[0] / r), 1.0 / (feature_map_size[1] / r)
+        cells = torch.tensor([(dj * j, di * i, dj * (j + 1), di * (i + 1))
+                              for i in range(nh) for j in range(nw)], dtype=torch.float32)
+        e = F.linear(cells, sd[p + "obj_bbox_2d_embedding.weight"],
+                     sd[p + "obj_bbox_2d_embedding.bias"])
+        out[f"image_patch_bbox_embedding_for_resolution{nh}"] = \
+            e[None].repeat_interleave(B, 0).permute(0, 2, 1)
+    out["key_padding_mask"] = (1 - batch["is_valid_obj"]).bool()
+    x = cls_emb + box3 + box2
+    i = 0
+    while f"{p}transform.resblocks.{i}.ln_1.weight" in sd:
+        q = f"{p}transform.resblocks.{i}"
+        a = F.linear(_ln(sd, q + ".ln_1", x), sd[q + ".attn.c_qkv.weight"], sd[q + ".attn.c_qkv.bias"])
+        a = F.linear(_xf_attention(a, num_heads), sd[q + ".attn.c_proj.weight"],
+                     sd[q + ".attn.c_proj.bias"])
+        x = x + a
+        m = F.linear(_ln(sd, q + ".ln_2", x), sd[q + ".mlp.c_fc.weight"], sd[q + ".mlp.c_fc.bias"])
+        x = x + F.linear(F.gelu(m), sd[q + ".mlp.c_proj.weight"], sd[q + ".mlp.c_proj.bias"])
+        i += 1
+    x = _ln(sd, p + "final_ln", x)
+    out["xf_proj"] = F.linear(x[:, 0], sd[p + "transformer_proj.weight"],
+                              sd[p + "transformer_proj.bias"])
+    out["xf_out"] = x.permute(0, 2, 1)
+    if "concat_cond" in batch:
+        cc = batch["concat_cond"]
+        if "autoregressive_cond" in batch:
+            cc = torch.cat([cc, batch["autoregressive_cond"]], dim=1)
+        out["concat_cond"] = cc
+    return out
+
+
+def _conv1d(sd, pre, x):
+    return F.conv1d(x, sd[pre + ".weight"], sd[pre + ".bias"])
+
+
+def object_aware_attention(sd, pre, x, cond, resolution):
+    """layout_unet_v1.py:416-532 (norm_first=False, channels_scale_for_positional_embedding=1)."""
+    B, C, H, W = x.shape
+    heads = C // 32
+    d = C // heads
+    L1 = H * W
+    xs = x.reshape(B, C, L1)
+    qkv = _conv1d(sd, pre + ".qkv_projector", gn32(sd, pre + ".norm_for_qkv", xs))
+    pos_img = gn32(sd, pre + ".norm_for_image_patch_positional_embedding",
+                   _conv1d(sd, pre + ".layout_position_embedding_projector",
+                           cond[f"image_patch_bbox_embedding_for_resolution{resolution}"]))
+    pos_lay = gn32(sd, pre + ".norm_for_layout_positional_embedding",
+                   _conv1d(sd, pre + ".layout_position_embedding_projector",
+                           cond["obj_bbox_embedding"]))
+    content = (cond["xf_out"] + gn32(sd, pre + ".norm_for_obj_class_embedding",
+                                     cond["obj_class_embedding"])) / 2
+    k_lay, v_lay = _conv1d(sd, pre + ".layout_content_embedding_projector", content).split(C, 1)
+    hv = lambda t: t.reshape(B * heads, d, -1)
+    q, k, v = [hv(t) for t in qkv.split(C, dim=1)]
+    pi, pl = hv(pos_img), hv(pos_lay)
+    qm = torch.cat([q, pi], 1)
+    km = torch.cat([torch.cat([k, pi], 1), torch.cat([hv(k_lay), pl], 1)], 2)
+    vm = torch.cat([v, hv(v_lay)], 2)
+    scale = 1 / math.sqrt(math.sqrt(2 * d))
+    w = torch.einsum("bct,bcs->bts", qm * scale, km * scale).float().softmax(-1)
+    a = torch.einsum("bts,bcs->bct", w, vm).reshape(B, C, L1)
+    return (xs + _conv1d(sd, pre + ".proj_out", a)).reshape(B, C, H, W)
+
+
+def res_block_v1(sd, pre, x, emb):
+    """layout_unet_v1.py:143-249 with use_scale_shift_norm=True; up/down discovered from keys."""
+    h = silu(gn32(sd, pre + ".in_layers.0", x))
+    if (pre + ".op.kernel") in sd:
+        up = float(sd[pre + ".op.kernel"].sum()) > 1.5  # up kernels are scaled by 2
+        rs = resample_up2 if up else resample_down2
+        h, x = rs(h), rs(x)
+    h = conv_sd(sd, pre + ".in_layers.2", h)
+    e = F.linear(silu(emb), sd[pre + ".emb_layers.1.weight"], sd[pre + ".emb_layers.1.bias"])
+    scale, shift = e[:, :, None, None].chunk(2, dim=1)
+    h = gn32(sd, pre + ".out_layers.0", h) * (1 + scale) + shift
+    h = conv_sd(sd, pre + ".out_layers.3", silu(h))
+    if (pre + ".skip_connection.weight") in sd:
+        x = F.conv2d(x, sd[pre + ".skip_connection.weight"], sd[pre + ".skip_connection.bias"])
+    return x + h
+
+
+def _run_sequential(sd, pre, h, emb, cond, image_size, ds):
+    """TimestepEmbedSequential (layout_unet_v1.py:63-78): children discovered from the keys."""
+    i = 0
+    while True:
+        q = f"{pre}.{i}"
+        if (q + ".in_layers.0.weight") in sd:
+            h = res_block_v1(sd, q, h, emb)
+            if (q + ".op.kernel") in sd:
+                ds = ds * 2 if float(sd[q + ".op.kernel"].sum()) < 1.5 else ds // 2
+        elif (q + ".qkv_projector.weight") in sd:
+            h = object_aware_attention(sd, q, h, cond, image_size // ds)
+        elif (q + ".weight") in sd and sd[q + ".weight"].ndim == 4:
+            h = conv_sd(sd, q, h)
+        else:
+            break
+        i += 1
+    return h, ds
+
+
+@torch.no_grad()
+def layout_unet_v1_forward(sd, x, log_snr, cond, *, image_size, model_channels=64, prefix=""):
+    """layout_unet_v1.py:866-902."""
+    p = prefix
+    B, _, H, W = x.shape
+    emb = time_mlp(sd, p + "time_embed", log_snr.float(), model_channels) + cond["xf_proj"]
+    h = x.float()
+    if "concat_cond" in cond:
+        h = torch.cat([h, cond["concat_cond"]], dim=1)
+    h = torch.cat([h, fourier_features(sd[p + "coords"], H, W).expand(B, -1, -1, -1)], dim=1)
+    hs, ds, i = [], 1, 0
+    while f"{p}input_blocks.{i}.0.weight" in sd or f"{p}input_blocks.{i}.0.in_layers.0.weight" in sd:
+        h, ds = _run_sequential(sd, f"{p}input_blocks.{i}", h, emb, cond, image_size, ds)
+        hs.append(h)
+        i += 1
+    h, ds = _run_sequential(sd, p + "middle_block", h, emb, cond, image_size, ds)
+    i = 0
+    while f"{p}output_blocks.{i}.0.in_layers.0.weight" in sd:
+        h = torch.cat([h, hs.pop()], dim=1)
+        h, ds = _run_sequential(sd, f"{p}output_blocks.{i}", h, emb, cond, image_size, ds)
+        i += 1
+    h = silu(gn32(sd, p + "out.0", h))
+    return conv_sd(sd, p + "out.2", h)

@@ -206,6 +206,74 @@ def sec_lidar():
     save("lidar", **out)
 
 
+def synth_layout_batch(B, H, W, seed, n_extra=0):
+    """Synthetic layout condition batch."""
+    from lidarcrafter_amd.testing import synth_layout_batch as f
+    return f(B, H, W, seed, n_extra)
+
+
+def _build_cond(res, image_size, model_channels, cond_out=10):
+    lu = R.ref("models.unets.layout_unet_v1")
+    le = R.ref("models.unets.layout_encoder")
+    lidar = R.ref("utils.lidar")
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = lu.LayoutUnetV1(in_channels=2 + cond_out, resolution=res, image_size=image_size,
+                            use_fp16=False, use_scale_shift_norm=True, out_channels=2,
+                            model_channels=model_channels, encoder_channels=64,
+                            num_head_channels=32, num_heads=-1, num_heads_upsample=-1,
+                            num_res_blocks=2, num_attention_blocks=1, resblock_updown=True,
+                            attention_ds=[4, 8], channel_mult=[1, 2, 4, 8], dropout=0.1,
+                            use_checkpoint=False, use_positional_embedding_for_attention=True,
+                            attention_block_type="ObjectAwareCrossAttention")
+    m.coords = lidar.get_linear_ray_angles(res[0], res[1], 10.0, -30.0)
+    enc = le.LayoutTransformerEncoder(
+        feature_map_size=list(res), used_condition_types=["obj_class", "obj_bbox", "is_valid_obj"],
+        layout_length=13, num_classes_for_layout_object=9, mask_size_for_layout_object=32,
+        hidden_dim=64, output_dim=model_channels * 4, num_layers=6, num_heads=4, use_final_ln=True,
+        use_positional_embedding=False, not_use_layout_fusion_module=False,
+        resolution_to_attention=[4, 8], use_key_padding_mask=False, out_channels=cond_out)
+    return seeded_fill(m, salt=200).eval(), seeded_fill(enc, salt=201).eval()
+
+
+def sec_cond_small():
+    m, enc = _build_cond((8, 64), 8, 32)
+    batch = synth_layout_batch(2, 8, 64, seed=51)
+    x = seeded_randn(2, 2, 8, 64, seed=52)
+    lam = torch.tensor([-3.0, 1.5])
+    with torch.no_grad():
+        cond = enc(batch)
+        y = m(x, {"time_condition": lam, "other_condition": cond})
+    out = {"y": y}
+    for k in ("xf_proj", "xf_out", "obj_class_embedding", "obj_bbox_embedding",
+              "image_patch_bbox_embedding_for_resolution2",
+              "image_patch_bbox_embedding_for_resolution1"):
+        out["cond_" + k] = cond[k]
+    out["keys_unet"] = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()))
+    out["keys_enc"] = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in enc.state_dict().items()))
+    save("cond_small", **out)
+
+
+def sec_cond_full():
+    """box-layout-v6 shapes: 32x1024, model_channels 64 (70.1 M params), B=1."""
+    df = R.ref("models.diffusion")
+    m, enc = _build_cond((32, 1024), 32, 64)
+    batch = synth_layout_batch(1, 32, 1024, seed=53)
+    x = seeded_randn(1, 2, 32, 1024, seed=54)
+    lam = torch.tensor([-0.5])
+    with torch.no_grad():
+        cond = enc(batch)
+        y = m(x, {"time_condition": lam, "other_condition": cond})
+    keys = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()))
+    out = {"y": y, "keys_unet": keys, "nparams": sum(p.numel() for p in m.parameters())}
+    # 3-step conditional DDIM trajectory through the reference sampler (C3 at B=1)
+    ddpm = df.CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval()
+    rng = [torch.Generator().manual_seed(7)]
+    xs = ddpm.sample(batch, 1, 3, progress=False, rng=rng, return_all=True, mode="ddim")
+    out["traj_x1"], out["traj_x3"] = xs[1], xs[3]
+    save("cond_full", **out)
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":
