@@ -45,8 +45,11 @@ def build_ddpm(device):
     return ddpm.eval().to(device), cfg
 
 
-def x_T_for(rank: int, shape):
-    g = [torch.Generator().manual_seed(rank * BATCH_PER_GPU + i) for i in range(BATCH_PER_GPU)]
+def x_T_for(rank: int, shape, world: int = 1):
+    """x_T of this rank's shard: per-sample CPU generators seeded with the GLOBAL sample index."""
+    from lidarcrafter_amd import parallel
+
+    g = parallel.shard_generators(BATCH_PER_GPU * world, rank, world)
     return torch.stack([torch.randn(*shape, generator=r) for r in g])
 
 
@@ -106,7 +109,7 @@ def main():
 
     ddpm, cfg = build_ddpm(device)
     total = args.warmup + args.steps
-    x_T = x_T_for(rank, ddpm.sampling_shape).to(device)
+    x_T = x_T_for(rank, ddpm.sampling_shape, world).to(device)
     st = ddpm.begin_sampling(BATCH_PER_GPU, total, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
 
     def sync():
@@ -122,8 +125,10 @@ def main():
         ddpm.sampling_step(st)
     frames = st["x"]
     if dist_on:  # reassemble the generated frames once, after the loop (RCCL all-gather)
-        gathered = [torch.empty_like(frames) for _ in range(world)]
-        dist.all_gather(gathered, frames.contiguous())
+        from lidarcrafter_amd import parallel
+
+        all_frames = parallel.gather_frames(frames, BATCH_PER_GPU * world)
+        assert all_frames.shape[0] == BATCH_PER_GPU * world
     sync()
     dt = time.perf_counter() - t0
     if dist_on:

@@ -1,0 +1,41 @@
+"""Point cloud -> range image -- API mirror of the reference's
+lidargen/dataset/transforms_3d/common.py (mask_points_with_distance :16-24,
+load_points_as_images :26-91 with scan_unfolding=False) on the HIP z-buffer kernel
+(lc_project_points): one atomic-min pass + one gather pass instead of numpy argsort + scatter."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from lidarcrafter_amd import ops as K
+
+
+def mask_points_with_distance(points: np.ndarray, min_depth: float = 1.45, max_depth: float = 80.0):
+    x = points[:, :3].astype(np.float32)
+    depth = np.sqrt((x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1]) + x[:, 2] * x[:, 2])
+    return (depth >= min_depth) & (depth <= max_depth)
+
+
+def load_points_as_images(point_path: str = None, points=None, scan_unfolding: bool = True,
+                          H: int = 64, W: int = 2048, min_depth: float = 1.45,
+                          max_depth: float = 80.0, fov_up: float = 10.0, fov_down: float = -30.0,
+                          custom_feat_dim: int = 0):
+    """-> float32 [H, W, 6] = (x, y, z, intensity, depth, mask).  numpy in -> numpy out, CUDA
+    tensor in -> CUDA tensor out (no host round trip).
+    All-float32 semantics of the reference's pinned numpy; equal-depth ties go to
+    the lowest point index."""
+    assert point_path is not None or points is not None, "Either point_path or points must be provided."
+    if scan_unfolding:
+        raise NotImplementedError("scan_unfolding=True (KITTI ring unfolding) is not used by any "
+                                  "nuScenes config; only the spherical projection is on the path")
+    if custom_feat_dim:
+        raise NotImplementedError("custom_feat_dim > 0 is not on the path")
+    if point_path is not None:
+        points = np.fromfile(point_path, dtype=np.float32).reshape(-1, 5)[:, :4]
+    is_numpy = isinstance(points, np.ndarray)
+    if not torch.cuda.is_available():
+        raise RuntimeError("load_points_as_images needs the MI355X: no CPU fallback on the hot path")
+    p = torch.from_numpy(np.ascontiguousarray(points[:, :4], np.float32)) if is_numpy else points
+    p = p[:, :4].float().contiguous().cuda()
+    img, _ = K.project_points(p, H, W, fov_up, fov_down, min_depth, max_depth)
+    return img.cpu().numpy() if is_numpy else img

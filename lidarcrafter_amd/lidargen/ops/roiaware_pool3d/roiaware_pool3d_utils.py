@@ -1,0 +1,53 @@
+"""Points-in-boxes -- API mirror of the reference's
+lidargen/ops/roiaware_pool3d/roiaware_pool3d_utils.py:9-45 on the HIP kernels
+(lc_points_in_boxes_mask / _index).  The reference's `points_in_boxes_cpu` runs a C++ double loop
+on the host (called >= 2x per frame in the temporal loop); here both entry points
+run on the GPU.  RoIAwarePool3d (voxel pooling, :48-107) is not called by any generation script
+and is not built yet."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from lidarcrafter_amd import ops as K
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("points_in_boxes needs the MI355X: the hot path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_torch(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x).float(), True
+    return x, False
+
+
+def points_in_boxes_cpu(points, boxes):
+    """points (M,3), boxes (N,7) [x,y,z,dx,dy,dz,heading] -> int (N,M) 0/1.
+    Same contract as the reference, INCLUDING its in-place `boxes[:, 3:6] += 0.2` on the caller's
+    tensor (a numpy input is inflated on its float32 copy, exactly like the reference) and the
+    host-side MARGIN of 1e-2; numpy in -> numpy out."""
+    assert boxes.shape[1] == 7 and points.shape[1] == 3
+    points, is_numpy = _to_torch(points)
+    boxes, _ = _to_torch(boxes)
+    boxes[:, 3:6] += boxes.new_tensor([0.2, 0.2, 0.2])[None, :]
+    dev = points.device if points.is_cuda else _device()
+    out = K.points_in_boxes_mask(points.float().to(dev), boxes.float().to(dev), 1e-2)
+    out = out if points.is_cuda else out.cpu()
+    return out.numpy() if is_numpy else out
+
+
+def points_in_boxes_gpu(points, boxes):
+    """points (B,M,3), boxes (B,T,7) -> int32 (B,M): index of the first containing box, -1 bg."""
+    assert boxes.shape[0] == points.shape[0]
+    assert boxes.shape[2] == 7 and points.shape[2] == 3
+    return K.points_in_boxes_index(points.float(), boxes.float(), 1e-5)
+
+
+class RoIAwarePool3d(torch.nn.Module):
+    def __init__(self, out_size, max_pts_each_voxel=128):
+        super().__init__()
+        raise NotImplementedError("RoIAwarePool3d: not on the generation path (SURVEY.md §8a-20); "
+                                  "voxel-pool kernels are a later row")

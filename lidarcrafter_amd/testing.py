@@ -102,3 +102,15 @@ def synth_layout_batch(B: int, H: int, W: int, seed: int, n_extra: int = 0) -> d
         out["autoregressive_cond"] = torch.from_numpy(
             g.uniform(0, 1, (B, n_extra, H, W)).astype(np.float32))
     return out
+
+
+def synth_boxes(n: int, pts, seed: int):
+    """n rotated boxes [x,y,z,dx,dy,dz,heading] centred on random points of `pts` (float32)."""
+    import numpy as np
+
+    g = np.random.default_rng(seed)
+    bx = np.stack([np.zeros(n), np.zeros(n), np.zeros(n), g.uniform(1.5, 10, n),
+                   g.uniform(1.5, 5, n), g.uniform(1.5, 4, n), g.uniform(-3.2, 3.2, n)],
+                  1).astype(np.float32)
+    bx[:, :3] = pts[g.integers(0, len(pts), n), :3]
+    return bx

@@ -274,6 +274,29 @@ def sec_cond_full():
     save("cond_full", **out)
 
 
+def synth_boxes(n, pts, seed):
+    from lidarcrafter_amd.testing import synth_boxes as f
+    return f(n, pts, seed)
+
+
+def sec_boxes():
+    """points_in_boxes_cpu of the REFERENCE C++ (oracle/_ref build of roiaware_pool3d.cpp) through
+    the reference's Python wrapper semantics (boxes[:, 3:6] += 0.2 in place, MARGIN 1e-2)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import build_c
+
+    build_c.build_ref()
+    ref = build_c.load_ref()
+    pts = synth_points(32768, 5)[:, :3].copy()
+    bx = synth_boxes(12, pts, 6)
+    infl = bx.copy()
+    infl[:, 3:6] += 0.2
+    out = torch.zeros(12, len(pts), dtype=torch.int32)
+    ref.points_in_boxes_cpu(torch.from_numpy(infl), torch.from_numpy(pts), out)
+    save("boxes", mask_packed=np.packbits(out.numpy().astype(np.uint8), axis=1),
+         count=int(out.sum()))
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":

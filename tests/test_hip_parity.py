@@ -393,3 +393,34 @@ def test_cond_full_golden(dev, golden):
     xs = ddpm.sample(batch, 1, 3, progress=False, rng=rng, return_all=True, mode="ddim").cpu()
     assert rel_l2(xs[1], T(g["traj_x1"])) < 1e-3, rel_l2(xs[1], T(g["traj_x1"]))
     assert rel_l2(xs[3], T(g["traj_x3"])) < 1e-3, rel_l2(xs[3], T(g["traj_x3"]))
+
+
+# ------------------------------------------------------------------------------------- boxes
+def test_points_in_boxes_bit_exact(dev, golden):
+    from lidarcrafter_amd.testing import synth_boxes
+    from lidargen.ops.roiaware_pool3d import roiaware_pool3d_utils as R
+    from oracle import boxes as OB
+
+    g = golden("boxes")
+    pts = synth_points(32768, 5)[:, :3].copy()
+    bx = synth_boxes(12, pts, 6)
+    keep = bx.copy()
+    mask = R.points_in_boxes_cpu(pts, bx)          # numpy in -> numpy out, runs on the GPU
+    assert isinstance(mask, np.ndarray) and mask.shape == (12, 32768)
+    assert np.array_equal(np.packbits(mask.astype(np.uint8), axis=1), g["mask_packed"])
+    # batched first-hit variant (GPU margin 1e-5), incl. an empty / far box and B=2
+    pts2 = np.stack([pts, synth_points(32768, 8)[:, :3]])
+    bx2 = np.stack([keep, synth_boxes(12, pts2[1], 11)])
+    bx2[1, 3, :3] = 1e4
+    idx = R.points_in_boxes_gpu(T(pts2).to(dev), T(bx2).to(dev))
+    assert np.array_equal(idx.cpu().numpy(), OB.points_in_boxes_index(pts2, bx2, 1e-5))
+
+
+def test_load_points_as_images_api(dev, golden):
+    from lidargen.dataset.transforms_3d.common import load_points_as_images
+    from oracle import lidar as L
+
+    pts = synth_points(4096, 0)
+    img = load_points_as_images(points=pts, scan_unfolding=False, H=16, W=256)
+    ref, _ = L.load_points_as_images(pts, 16, 256, mode="f32")
+    assert isinstance(img, np.ndarray) and np.array_equal(img, ref)
