@@ -31,6 +31,7 @@ import torch  # noqa: E402
 BATCH_PER_GPU = 8
 RES = (32, 1024)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/f16 MFMA dense peak (~2.5 PF)
 GFLOP_PER_SAMPLE_STEP = 116.6  # SURVEY.md §8(d), uncond 32x1024 (114.4 conv + 2.15 MHA)
 
 
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--conv-precision", choices=["f32", "f16x2"], default=None,
+                    help="override LC_CONV_PRECISION (default f16x2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +110,8 @@ def main():
 
     from lidarcrafter_amd import ops as K
 
+    if args.conv_precision:
+        K.set_conv_precision(args.conv_precision)
     ddpm, cfg = build_ddpm(device)
     total = args.warmup + args.steps
     x_T = x_T_for(rank, ddpm.sampling_shape, world).to(device)
@@ -158,9 +163,17 @@ def main():
             a[2] += 1
         w, t, n = fam["conv3x3"]
         achieved = w / t / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_ring_kernel<KS=3> (all tile instantiations)",
-                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        split = K.CONV_PRECISION == "f16x2"
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        roof = {"bound": "mfma",
+                "kernel": ("conv_f16x2_kernel<KS=3>" if split else "conv_ring_kernel<KS=3>") +
+                          " (all tile instantiations)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "note": ("achieved counts ALGORITHMIC flops (2*MACs); the f16x2 split issues 3 "
+                         "f16 MFMAs per product, so the attainable ceiling of this kernel is "
+                         "peak/3 = 833 TFLOP/s" if split else
+                         "fp32 MFMA (exact fp32), peak = fp32 matrix peak"),
                 "launches_per_step": n // n_prof,
                 "avg_launch_us": round(t / n * 1e6, 1),
                 "flop_per_launch": round(w / n),
@@ -179,7 +192,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f16x2-split MFMA, fp32 accumulate (fp32-class accuracy)"
+                      if K.CONV_PRECISION == "f16x2" else "f32"), "data": "synthetic",
             "config": {"workload": "C2: EfficientUNet nuscenes-unet-uncond (31.1M params, seeded "
                                    "random init), 32x1024, DDIM eta=0, batch 8 per GPU, "
                                    f"{total}-step schedule ({args.warmup} warmup + {args.steps} timed)",

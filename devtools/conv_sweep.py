@@ -6,6 +6,8 @@ sys.path.insert(0, ".")
 from lidarcrafter_amd import ops as K
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
+CFGS = (1, 2, 3, 4, 5)
 dev = torch.device("cuda:0")
 shapes = [  # Ci, Co, H, W, ks
     (32, 64, 32, 1024, 3), (64, 64, 32, 1024, 3), (64, 128, 32, 1024, 3), (128, 64, 32, 1024, 3),
@@ -22,15 +24,15 @@ for (Ci, Co, H, W, ks) in shapes:
     out = torch.empty(B, Co, H, W, device=dev)
     fl = 2.0 * B * H * W * Co * Ci * ks * ks
     line = f"Ci{Ci:4d} Co{Co:4d} {H:2d}x{W:4d} k{ks}: "
-    for cfg in (1, 2, 3, 4, 5):
+    for cfg in CFGS:
         try:
             for _ in range(3):
-                K.conv2d_ring(x, pk, w, b, out=out, tile_cfg=cfg)
+                K.conv2d_ring(x, pk, w, b, out=out, tile_cfg=cfg, precision=PREC)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                K.conv2d_ring(x, pk, w, b, out=out, tile_cfg=cfg)
+                K.conv2d_ring(x, pk, w, b, out=out, tile_cfg=cfg, precision=PREC)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 10
             line += f" c{cfg}:{ms*1e3:7.0f}us {fl/ms/1e9:5.1f}TF |"

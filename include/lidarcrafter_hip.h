@@ -57,6 +57,22 @@ int lc_conv2d_ring_fwd(const float* x, int64_t x_bs, const float* wp, const floa
                        int tile_cfg /* 0 = auto */, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
+ * Same convolution on the f16 matrix cores with fp32-class accuracy ("f16x2 split"): operands are
+ * split into hi+lo fp16 halves (activations on the fly, weights at pack time) and
+ * xh*wh + xh*wl + xl*wh is accumulated in fp32 by three v_mfma_f32_32x32x16_f16 per block --
+ * ~5e-7 relative error per product, 5.3x the fp32 matrix peak.  Packed weights: two planes
+ * (hi, lo) of lc_packed_conv_weight_f16x2_elems() fp16 values each, layout [tap][Ci^16/8][Co^64][8].
+ * Arguments otherwise identical to lc_conv2d_ring_fwd.
+ * ------------------------------------------------------------------------------------------- */
+int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks);
+int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
+                              lc_stream_t s);
+int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, const void* wp_lo,
+                             const float* bias, const float* res, int64_t res_bs, float* y,
+                             int64_t y_bs, int B, int Ci, int Co, int H, int W, int ks,
+                             float out_scale, int tile_cfg /* 0 = auto */, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
  * GroupNorm (+ affine | + AdaGN scale/shift) (+ SiLU):
  *   nn.GroupNorm(8, C, 1e-6) efficient_unet.py:37,77; ops.AdaGN ops.py:176-200;
  *   GroupNorm32 nn.py:17-19 + scale-shift norm layout_unet_v1.py:243-245; nn.SiLU.

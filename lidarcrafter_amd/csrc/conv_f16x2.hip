@@ -1,0 +1,319 @@
+// Ring-padded 3x3 / 1x1 convolution on the f16 matrix cores with fp32-class accuracy
+// ("f16x2 split"): every fp32 operand is split on the fly into hi + lo halves,
+//     x*16 = xh + xl,   w*256 = wh + wl      (xh = fp16(x*16), xl = fp16(x*16 - xh), ...)
+// and the product is accumulated in fp32 as  xh*wh + xh*wl + xl*wh  (three
+// v_mfma_f32_32x32x16_f16 per 32x32x16 block; the dropped xl*wl term is 2^-22 relative).
+// The power-of-two pre-scales keep the lo parts in fp16's normal range for activations down to
+// ~1e-2 and weights down to ~1e-3 and are undone exactly (x 2^-12) in the epilogue.
+// Per-product relative error ~5e-7 (fp32 rounding: 6e-8) at 3/16 of the fp32-MFMA instruction
+// cost: 16x rate / 3 passes = 5.3x the fp32 matrix peak.
+//
+// Same implicit-GEMM mapping as conv.hip (A rows = 32 output channels, B cols = 32 consecutive W
+// pixels) but K = 16 input channels per MFMA, which needs channel-innermost operands: lane l
+// supplies A[i=l&31][k=8*(l>>5)..+7], B[k=8*(l>>5)..+7][j=l&31] as one 16-byte vector.
+//   weights : packed once per weight version as wh/wl[tap][Ci/8][Co^64][8] (lc_pack_conv_weight_f16x2)
+//   input   : stays fp32 NCHW in HBM; the staging pass loads 8 channel planes per pixel
+//             (coalesced along W), splits, and writes [cb][row][col] 16-byte units into LDS.
+// Reference semantics: ops.Conv2d + ops.Pad, lidargen/models/unets/ops.py:32-49,149-173.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr float X_PRESCALE = 16.0f, W_PRESCALE = 256.0f, OUT_UNSCALE = 1.0f / 4096.0f;
+
+struct ConvArgsH {
+    const float* x;
+    const half8* wh;
+    const half8* wl;
+    const float* bias;
+    const float* res;
+    float* y;
+    long long x_bs, res_bs, y_bs;
+    int B, Ci, Co, H, W, Cib, Cop;
+    int tiles_h, tiles_w;
+    float out_scale;
+};
+
+template <int WCO, int WPX, int TCO, int TPX, int TH, int TW, int KS>
+struct HCfg {
+    static constexpr int WCO_ = WCO, WPX_ = WPX, TCO_ = TCO, TPX_ = TPX, TH_ = TH, TW_ = TW;
+    static constexpr int CB = 2;                        // 8-channel blocks per K chunk (16 ch)
+    static constexpr int HALO = KS / 2;
+    static constexpr int NTAP = KS * KS;
+    static constexpr int BN = WCO * TCO * 32;
+    static constexpr int NPT = WPX * TPX;
+    static constexpr int TPR = TW / 32;
+    static constexpr int XR = TH + 2 * HALO;
+    static constexpr int XW = TW + 2 * HALO;
+    static constexpr int XU = CB * XR * XW;             // 16-byte x units per plane per chunk
+    static constexpr int NXU = (XU + 255) / 256;
+    static constexpr int WU = NTAP * CB * BN;           // 16-byte weight units per plane
+    static constexpr int NWU = (WU + 255) / 256;
+    static_assert(NPT * 32 == TH * TW, "tile shape");
+    static_assert(WCO * WPX == 4, "4 waves");
+};
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float s = v[k] * X_PRESCALE;
+        s = fminf(fmaxf(s, -60000.0f), 60000.0f);       // never inf in fp16
+        const _Float16 h = (_Float16)s;
+        hi[k] = h;
+        lo[k] = (_Float16)(s - (float)h);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
+    constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
+    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
+    constexpr int KS = 2 * HALO + 1;
+    __shared__ half8 lds[2 * XU + 2 * WU];
+    half8* xh = lds;
+    half8* xl = lds + XU;
+    half8* wh = lds + 2 * XU;
+    half8* wl = lds + 2 * XU + WU;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / C::WPX_, wpx = wave % C::WPX_;
+
+    int bx = blockIdx.x;
+    const int tw_i = bx % a.tiles_w; bx /= a.tiles_w;
+    const int th_i = bx % a.tiles_h; bx /= a.tiles_h;
+    const int b = bx;
+    const int h0 = th_i * C::TH_, w0 = tw_i * C::TW_;
+    const int co0 = blockIdx.y * BN;
+    const int H = a.H, W = a.W;
+    const long long HW = (long long)H * W;
+    const float* xb = a.x + (long long)b * a.x_bs;
+
+    int x_off[NXU];  // (cb << 24 | plane offset) or -1 for padding
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+        const int e = tid + i * 256;
+        const int cb = e / (XR * XW);
+        const int rem = e - cb * (XR * XW);
+        const int r = rem / XW, c = rem - r * XW;
+        const int gh = h0 - HALO + r;
+        int gw = w0 - HALO + c;
+        gw %= W; if (gw < 0) gw += W;
+        const bool ok = (e < XU) && gh >= 0 && gh < H;
+        x_off[i] = ok ? ((cb << 24) | (gh * W + gw)) : -1;
+    }
+
+    float xr[NXU][8];
+    half8 whr[NWU], wlr[NWU];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NXU; ++i) {
+            const int cbase = c0 + 8 * (x_off[i] >> 24);
+            const float* p = xb + (long long)cbase * HW + (x_off[i] & 0xFFFFFF);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                xr[i][k] = (x_off[i] >= 0 && cbase + k < a.Ci) ? p[(long long)k * HW] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int e = tid + i * 256;
+            if (e < WU) {
+                const int row = e / BN;                    // tap*CB + cb
+                const int cu = e - row * BN;
+                const int tap = row / CB, cb = row - tap * CB;
+                const long long idx = ((long long)tap * a.Cib + (c0 >> 3) + cb) * a.Cop + co0 + cu;
+                whr[i] = a.wh[idx];
+                wlr[i] = a.wl[idx];
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXU; ++i) {
+            const int e = tid + i * 256;
+            if (e < XU) {
+                half8 hi, lo;
+                split8(xr[i], hi, lo);
+                xh[e] = hi;
+                xl[e] = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            const int e = tid + i * 256;
+            if (e < WU) { wh[e] = whr[i]; wl[e] = wlr[i]; }
+        }
+    };
+
+    f32x16 acc[C::TCO_][C::TPX_];
+#pragma unroll
+    for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TPX_; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int kh = lane >> 5, l31 = lane & 31;
+    int xbase[C::TPX_];
+#pragma unroll
+    for (int j = 0; j < C::TPX_; ++j) {
+        const int t = wpx * C::TPX_ + j;
+        const int tr = t / C::TPR, tc = t - tr * C::TPR;
+        xbase[j] = kh * (XR * XW) + tr * XW + tc * 32 + l31;
+    }
+    const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
+
+    const int nchunk = a.Cib / CB;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) load_chunk((ch + 1) * 8 * CB);
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+            half8 ah[C::TCO_], al[C::TCO_], bh[C::TPX_], bl[C::TPX_];
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i) {
+                ah[i] = wh[tap * CB * BN + wbase + i * 32];
+                al[i] = wl[tap * CB * BN + wbase + i * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < C::TPX_; ++j) {
+                bh[j] = xh[xbase[j] + dy * XW + dx];
+                bl[j] = xl[xbase[j] + dy * XW + dx];
+            }
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    float* yb = a.y + (long long)b * a.y_bs;
+    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+#pragma unroll
+    for (int j = 0; j < C::TPX_; ++j) {
+        const int t = wpx * C::TPX_ + j;
+        const int tr = t / C::TPR, tc = t - tr * C::TPR;
+        const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+        const bool pok = gh < H && gw < W;
+        const long long poff = (long long)gh * W + gw;
+#pragma unroll
+        for (int i = 0; i < C::TCO_; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wco * C::TCO_ + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (pok && co < a.Co) {
+                    float v = acc[i][j][r] * OUT_UNSCALE;
+                    if (a.bias) v += a.bias[co];
+                    if (rb) v += rb[(long long)co * HW + poff];
+                    yb[(long long)co * HW + poff] = v * a.out_scale;
+                }
+            }
+        }
+    }
+}
+
+template <class C>
+int launch_h(ConvArgsH a, hipStream_t st) {
+    a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
+    a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
+    dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
+    hipLaunchKernelGGL(conv_f16x2_kernel<C>, grid, dim3(256), 0, st, a);
+    return lc_launch_status();
+}
+
+template <int KS>
+int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
+    switch (cfg) {
+        case 1: return launch_h<HCfg<2, 2, 2, 2, 2, 64, KS>>(a, st);   // 128 co x 128 px
+        case 2: return launch_h<HCfg<1, 4, 2, 2, 4, 64, KS>>(a, st);   //  64 co x 256 px
+        case 3: return launch_h<HCfg<2, 2, 1, 1, 2, 32, KS>>(a, st);   //  64 co x  64 px
+        case 4: return launch_h<HCfg<2, 2, 2, 2, 4, 32, KS>>(a, st);   // 128 co x 128 px (4x32)
+        case 5: return launch_h<HCfg<1, 4, 2, 1, 2, 64, KS>>(a, st);   //  64 co x 128 px
+        default: return LC_EUNSUP;
+    }
+}
+
+int auto_cfg_h(int B, int Co, int H, int W) {
+    // Measured on MI355X at batch 8 (profiles/r01_b_conv_sweep_f16x2_b8.txt): the 64co x 256px block
+    // (cfg 2, 62 KB LDS, 2 blocks/CU) is best (213-318 TF effective) whenever it still yields
+    // >= 256 blocks; the 128-co blocks need 90 KB LDS (1 block/CU) and lose; small problems
+    // (L3: 4x128 px) want the 64x64 block (cfg 3) to fill the 256 CUs.
+    const long long px = (long long)B * H * W;
+    auto blocks = [&](int bn, int pxb) { return ((Co + bn - 1) / bn) * ((px + pxb - 1) / pxb); };
+    if (H % 4 == 0 && W % 64 == 0 && blocks(64, 256) >= 256) return 2;
+    if (H % 2 == 0 && W % 64 == 0 && blocks(64, 128) >= 512) return 5;
+    return 3;
+}
+
+__global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __restrict__ ph,
+                                     _Float16* __restrict__ pl, int Co, int Ci, int ntap, int Cib,
+                                     int Cop) {
+    const long long n = (long long)ntap * Cib * Cop * 8;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int k = e & 7;
+        long long r = e >> 3;
+        const int co = r % Cop; r /= Cop;
+        const int cb = r % Cib;
+        const int tap = r / Cib;
+        const int ci = cb * 8 + k;
+        float v = (co < Co && ci < Ci) ? w[((long long)co * Ci + ci) * ntap + tap] * W_PRESCALE : 0.0f;
+        v = fminf(fmaxf(v, -60000.0f), 60000.0f);
+        const _Float16 h = (_Float16)v;
+        ph[e] = h;
+        pl[e] = (_Float16)(v - (float)h);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks) {
+    const int64_t Cip = (Ci + 15) / 16 * 16, Cop = (Co + 63) / 64 * 64;
+    return (int64_t)ks * ks * Cip * Cop;  // halves per plane (hi and lo planes each this size)
+}
+
+extern "C" int lc_pack_conv_weight_f16x2(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci,
+                                         int ks, lc_stream_t s) {
+    if (!w || !wp_hi || !wp_lo || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3)) return LC_EINVAL;
+    const int Cib = (Ci + 15) / 16 * 2, Cop = (Co + 63) / 64 * 64;
+    const long long n = (long long)ks * ks * Cib * Cop * 8;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_h_kernel, dim3(blocks), dim3(256), 0, lc_s(s), w,
+                       (_Float16*)wp_hi, (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop);
+    return lc_launch_status();
+}
+
+extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi,
+                                        const void* wp_lo, const float* bias, const float* res,
+                                        int64_t res_bs, float* y, int64_t y_bs, int B, int Ci,
+                                        int Co, int H, int W, int ks, float out_scale, int tile_cfg,
+                                        lc_stream_t s) {
+    if (!x || !wp_hi || !wp_lo || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0)
+        return LC_EINVAL;
+    if (ks != 1 && ks != 3) return LC_EUNSUP;
+    if ((long long)H * W >= (1 << 24)) return LC_EUNSUP;
+    ConvArgsH a;
+    a.x = x; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
+    a.y = y; a.x_bs = x_bs; a.res_bs = res_bs; a.y_bs = y_bs;
+    a.B = B; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W;
+    a.Cib = (Ci + 15) / 16 * 2; a.Cop = (Co + 63) / 64 * 64;
+    a.out_scale = out_scale;
+    a.tiles_h = a.tiles_w = 0;
+    if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Co, H, W);
+    return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
+}

@@ -73,16 +73,33 @@ class _Timed:
 
 
 # ------------------------------------------------------------------------------------ conv
-class PackedConv:
-    """Packed copy wp[tap][Cip][Cop] of an OIHW conv weight, rebuilt when the parameter changes."""
+import os as _os
 
-    __slots__ = ("wp", "Co", "Ci", "ks", "_key")
+# Arithmetic of the convolution kernels:
+#   "f32"   : v_mfma_f32_32x32x2_f32, exact fp32 (== fmaf chain), 157 TFLOP/s peak
+#   "f16x2" : hi/lo fp16 split, 3 x v_mfma_f32_32x32x16_f16 per block, ~5e-7 relative per product
+CONV_PRECISION = _os.environ.get("LC_CONV_PRECISION", "f16x2")
+
+
+def set_conv_precision(mode: str) -> str:
+    global CONV_PRECISION
+    if mode not in ("f32", "f16x2"):
+        raise ValueError(mode)
+    old, CONV_PRECISION = CONV_PRECISION, mode
+    return old
+
+
+class PackedConv:
+    """Packed copies of an OIHW conv weight for the MFMA kernels (fp32 wp[tap][Ci^8][Co^64] and/or
+    the f16x2 hi/lo planes), rebuilt when the parameter changes."""
+
+    __slots__ = ("wp", "wh", "wl", "Co", "Ci", "ks", "_key", "_w4")
 
     def __init__(self):
-        self.wp = None
+        self.wp = self.wh = self.wl = None
         self._key = None
 
-    def get(self, weight: torch.Tensor) -> torch.Tensor:
+    def _refresh(self, weight: torch.Tensor):
         _req(weight, "weight")
         key = (weight.data_ptr(), weight._version, tuple(weight.shape))
         if key != self._key:
@@ -92,21 +109,42 @@ class PackedConv:
             Co, Ci, kh, kw = w.shape
             if kh != kw or kh not in (1, 3):
                 raise ValueError(f"only 1x1 / 3x3 kernels, got {tuple(w.shape)}")
-            n = lib().lc_packed_conv_weight_elems(Co, Ci, kh)
-            wp = torch.empty(n, device=w.device, dtype=_F32)
-            check(lib().lc_pack_conv_weight(w.contiguous().data_ptr(), wp.data_ptr(), Co, Ci, kh,
-                                            _stream()), "lc_pack_conv_weight")
-            self.wp, self.Co, self.Ci, self.ks, self._key = wp, Co, Ci, kh, key
+            self.Co, self.Ci, self.ks, self._key = Co, Ci, kh, key
+            self._w4 = w.contiguous()
+            self.wp = self.wh = self.wl = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        self._refresh(weight)
+        if self.wp is None:
+            n = lib().lc_packed_conv_weight_elems(self.Co, self.Ci, self.ks)
+            self.wp = torch.empty(n, device=weight.device, dtype=_F32)
+            check(lib().lc_pack_conv_weight(self._w4.data_ptr(), self.wp.data_ptr(), self.Co,
+                                            self.Ci, self.ks, _stream()), "lc_pack_conv_weight")
         return self.wp
+
+    def get_f16x2(self, weight: torch.Tensor):
+        self._refresh(weight)
+        if self.wh is None:
+            n = lib().lc_packed_conv_weight_f16x2_elems(self.Co, self.Ci, self.ks)
+            self.wh = torch.empty(n, device=weight.device, dtype=torch.float16)
+            self.wl = torch.empty(n, device=weight.device, dtype=torch.float16)
+            check(lib().lc_pack_conv_weight_f16x2(self._w4.data_ptr(), self.wh.data_ptr(),
+                                                  self.wl.data_ptr(), self.Co, self.Ci, self.ks,
+                                                  _stream()), "lc_pack_conv_weight_f16x2")
+        return self.wh, self.wl
 
 
 def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, out_scale: float = 1.0,
-                tile_cfg: int = 0) -> torch.Tensor:
+                tile_cfg: int = 0, precision: Optional[str] = None) -> torch.Tensor:
     """y = (conv_ring(x, W) + bias [+ res]) * out_scale.  ops.py:149-173 of the reference."""
     x_bs = _bs4(x, "x")
-    wp = packed.get(weight)
+    prec = precision or CONV_PRECISION
+    if prec == "f16x2":
+        wh, wl = packed.get_f16x2(weight)
+    else:
+        wp = packed.get(weight)
     B, Ci, H, W = x.shape
     if Ci != packed.Ci:
         raise ValueError(f"conv: input has {Ci} channels, weight expects {packed.Ci}")
@@ -125,10 +163,17 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
         _req(bias, "bias")
     ks = packed.ks
     with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks):
-        check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res), r_bs,
-                                       out.data_ptr(), y_bs, B, Ci, Co, H, W, ks,
-                                       float(out_scale), int(tile_cfg), _stream()),
-              "lc_conv2d_ring_fwd")
+        if prec == "f16x2":
+            check(lib().lc_conv2d_ring_f16x2_fwd(x.data_ptr(), x_bs, wh.data_ptr(), wl.data_ptr(),
+                                                 _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
+                                                 Ci, Co, H, W, ks, float(out_scale),
+                                                 int(tile_cfg), _stream()),
+                  "lc_conv2d_ring_f16x2_fwd")
+        else:
+            check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res),
+                                           r_bs, out.data_ptr(), y_bs, B, Ci, Co, H, W, ks,
+                                           float(out_scale), int(tile_cfg), _stream()),
+                  "lc_conv2d_ring_fwd")
     return out
 
 

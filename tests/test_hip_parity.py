@@ -31,7 +31,8 @@ def dev():
     (2, 42, 64, 8, 64, 3), (1, 512, 256, 4, 128, 1), (2, 48, 144, 1, 8, 3), (3, 16, 32, 2, 16, 3),
 ])
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
-def test_conv(dev, B, Ci, Co, H, W, ks, cfg):
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+def test_conv(dev, B, Ci, Co, H, W, ks, cfg, prec):
     from lidarcrafter_amd import ops as K
     from oracle import denoiser as D
 
@@ -42,8 +43,24 @@ def test_conv(dev, B, Ci, Co, H, W, ks, cfg):
     ref = (D.conv_ring(x, w, b) + res) * 0.7071
     pk = K.PackedConv()
     y = K.conv2d_ring(x.to(dev), pk, w.to(dev), b.to(dev), res=res.to(dev), out_scale=0.7071,
-                      tile_cfg=cfg)
+                      tile_cfg=cfg, precision=prec)
     assert rel_l2(y, ref) < 2e-6, rel_l2(y, ref)
+
+
+def test_conv_f16x2_accuracy_vs_fp64(dev):
+    """Split-fp16 conv error vs an fp64 reference is of fp32 class (not fp16 class ~5e-4), also
+    for small-magnitude weights/activations (lo parts near fp16's subnormal range)."""
+    from lidarcrafter_amd import ops as K
+
+    for xs, ws in ((1.0, 1.0), (0.05, 0.02), (30.0, 4.0)):
+        x = seeded_randn(2, 256, 8, 64, seed=40) * xs
+        w = seeded_randn(128, 256, 3, 3, seed=41) * ws / 48.0
+        ref = torch.nn.functional.conv2d(
+            torch.nn.functional.pad(torch.cat([x[..., -1:], x, x[..., :1]], -1).double(),
+                                    (0, 0, 1, 1)), w.double())
+        e16 = rel_l2(K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev), precision="f16x2"), ref)
+        e32 = rel_l2(K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev), precision="f32"), ref)
+        assert e16 < 2e-6 and e32 < 1e-6, (xs, ws, e16, e32)
 
 
 def test_conv_strided_views(dev):
