@@ -227,6 +227,262 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant (one 4-wave block per CU, LDS double buffered, one barrier per K chunk):
+//   iteration ch:  [LDS-DMA weights(ch+1) -> buf^1]  [buffer loads x(ch+2) -> register set B]
+//                  MFMAs of chunk ch from buf  ||  split+store of register set A (x(ch+1)) -> buf^1
+//   The VALU split / ds_write work sits in the same basic block as the MFMAs, so it issues in
+//   the shadow of the matrix pipe instead of between barriers (PMC of the first version: 33 %
+//   MFMA busy, 35 % of wave time issuing VALU/LDS, 33 % waiting).
+// x loads are raw buffer loads: the descriptor covers exactly the Ci*H*W floats of sample b, so
+// channel tails and H padding (offset forced out of range) read as 0 with no per-load predication
+// and no 64-bit address arithmetic.
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+__device__ __forceinline__ void split_store(const float (&v)[8], half8* dst_hi, half8* dst_lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    half8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const float s0 = v[k] * X_PRESCALE, s1 = v[k + 1] * X_PRESCALE;
+        // hi = s truncated to 11 significant bits (exact in fp32), lo = s - hi (exact), then
+        // hi converts exactly (round-toward-zero pack never overflows to inf), lo rounds RTNE.
+        const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+        const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+        const h2 ph = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+        f2 r; r.x = s0 - h0; r.y = s1 - h1;
+        const h2 pl = __builtin_convertvector(r, h2);
+        hi[k] = ph.x; hi[k + 1] = ph.y; lo[k] = pl.x; lo[k + 1] = pl.y;
+    }
+    *dst_hi = hi;
+    *dst_lo = lo;
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void conv_f16x2_pipe_kernel(ConvArgsH a) {
+    constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
+    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
+    constexpr int KS = 2 * HALO + 1;
+    // LDS planes are padded to whole 256-thread passes so that every thread always loads and
+    // stores (no exec-mask branches inside the K loop: the whole chunk is one basic block and
+    // hipcc can interleave ds_write/VALU with the MFMAs and count its vmcnt waits exactly).
+    constexpr int XUP = NXU * 256, WUP = NWU * 256;
+    constexpr int BUF = 2 * XUP + 2 * WUP;             // half8 units per LDS buffer
+    __shared__ half8 lds[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / C::WPX_, wpx = wave % C::WPX_;
+
+    int bx = blockIdx.x;
+    const int tw_i = bx % a.tiles_w; bx /= a.tiles_w;
+    const int th_i = bx % a.tiles_h; bx /= a.tiles_h;
+    const int b = bx;
+    const int h0 = th_i * C::TH_, w0 = tw_i * C::TW_;
+    const int co0 = blockIdx.y * BN;
+    const int H = a.H, W = a.W;
+    const int HW = H * W;
+    const float* xb = a.x + (long long)b * a.x_bs;
+    const unsigned nbytes = (unsigned)a.Ci * (unsigned)HW * 4u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, nbytes, 0x00020000);
+
+    unsigned x_voff[NXU];  // byte offset of (channel-block cb, pixel) inside the sample; OOB = pad
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+        const int e = tid + i * 256;
+        const int cb = e / (XR * XW);
+        const int rem = e - cb * (XR * XW);
+        const int r = rem / XW, c = rem - r * XW;
+        const int gh = h0 - HALO + r;
+        int gw = w0 - HALO + c;
+        gw %= W; if (gw < 0) gw += W;
+        const bool ok = (e < XU) && gh >= 0 && gh < H;
+        x_voff[i] = ok ? (unsigned)(cb * 8 * HW + gh * W + gw) * 4u : 0xFFFFFFF0u;
+    }
+    long long w_idx[NWU];  // unit index of this thread's weight units for chunk 0
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) {
+        int e = tid + i * 256;
+        if (e >= WU) e = WU - 1;                        // padding units duplicate the last one
+        const int row = e / BN, cu = e - row * BN;
+        const int tap = row / CB, cb = row - tap * CB;
+        w_idx[i] = ((long long)tap * a.Cib + cb) * a.Cop + co0 + cu;
+    }
+    const long long w_chunk = (long long)CB * a.Cop;    // unit stride between K chunks
+
+    auto load_x = [&](float (&xr)[NXU][8], int ch) {
+#pragma unroll
+        for (int i = 0; i < NXU; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                xr[i][k] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, x_voff[i],
+                                                                (unsigned)(ch * 16 + k) * HW * 4u, 0));
+    };
+    auto load_w = [&](half8 (&wr)[2 * NWU], int ch) {
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) {
+            wr[2 * i] = a.wh[w_idx[i] + ch * w_chunk];
+            wr[2 * i + 1] = a.wl[w_idx[i] + ch * w_chunk];
+        }
+    };
+
+    f32x16 acc[C::TCO_][C::TPX_];
+#pragma unroll
+    for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TPX_; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int kh = lane >> 5, l31 = lane & 31;
+    int xbase[C::TPX_];
+#pragma unroll
+    for (int j = 0; j < C::TPX_; ++j) {
+        const int t = wpx * C::TPX_ + j;
+        const int tr = t / C::TPR, tc = t - tr * C::TPR;
+        xbase[j] = kh * (XR * XW) + tr * XW + tc * 32 + l31;
+    }
+    const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
+
+    auto store_tap_x = [](int i) {   // constexpr-foldable
+        const int first = NTAP > NXU + 2 ? NTAP - NXU - 2 : 0;
+        const int t = first + i;
+        return t < NTAP ? t : NTAP - 1;
+    };
+    auto store_tap_w = [](int i) {
+        const int t = NTAP - 1 - (NWU - 1 - i) / 2;
+        return t > 0 ? t : 0;
+    };
+    auto store_x = [&](half8* buf, const float (&xr)[NXU][8], int i) {
+        split_store(xr[i], buf + tid + i * 256, buf + XUP + tid + i * 256);
+    };
+    auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
+        buf[2 * XUP + tid + i * 256] = wr[2 * i];
+        buf[2 * XUP + WUP + tid + i * 256] = wr[2 * i + 1];
+    };
+    // one chunk of MFMAs from `cur`; the split+store of the NEXT chunk's registers into `nxt`
+    // is spread over the taps (same basic block as the MFMAs)
+    auto compute = [&](const half8* cur, half8* nxt, const float (&xr)[NXU][8],
+                       const half8 (&wr)[2 * NWU]) {
+        const half8* cxh = cur;
+        const half8* cxl = cur + XUP;
+        const half8* cwh = cur + 2 * XUP;
+        const half8* cwl = cwh + WUP;
+        // operand fragments are software pipelined ONE TAP AHEAD (two register sets, static
+        // parity after unrolling): with one wave per SIMD nothing else hides the LDS latency.
+        half8 ah[2][C::TCO_], al[2][C::TCO_], bh[2][C::TPX_], bl[2][C::TPX_];
+        auto fetch = [&](int tap, int s) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i) {
+                ah[s][i] = cwh[tap * CB * BN + wbase + i * 32];
+                al[s][i] = cwl[tap * CB * BN + wbase + i * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < C::TPX_; ++j) {
+                bh[s][j] = cxh[xbase[j] + dy * XW + dx];
+                bl[s][j] = cxl[xbase[j] + dy * XW + dx];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int s = tap & 1;
+            if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // loads of this chunk's successor were issued before tap 0; consume them as late as
+            // possible: x units over taps [T0, T0+NXU), weight units over the last taps.
+            // (A finer sched_group_barrier interleave was measured 3-10 % slower than letting
+            // hipcc schedule each tap region on its own.)
+#pragma unroll
+            for (int i = 0; i < NXU; ++i)
+                if (tap == store_tap_x(i)) store_x(nxt, xr, i);
+#pragma unroll
+            for (int i = 0; i < NWU; ++i)
+                if (tap == store_tap_w(i)) store_w(nxt, wr, i);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    half8* cur = lds;
+    half8* nxt = lds + BUF;
+    const int nchunk = a.Cib / CB;
+    const int last = nchunk - 1;
+    float xr[NXU][8];
+    half8 wr[2 * NWU];
+    // prologue: chunk 0 -> cur
+    load_x(xr, 0);
+    load_w(wr, 0);
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) store_x(cur, xr, i);
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) store_w(cur, wr, i);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // issue the loads of chunk ch+1 (clamped: unconditional), run the MFMAs of chunk ch and
+        // store the loaded chunk into the other buffer during the last taps; one barrier.
+        load_x(xr, min(ch + 1, last));
+        load_w(wr, min(ch + 1, last));
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc would
+                                             // otherwise sink every load next to its use)
+        compute(cur, nxt, xr, wr);
+        __syncthreads();
+        half8* t = cur; cur = nxt; nxt = t;
+    }
+
+    float* yb = a.y + (long long)b * a.y_bs;
+    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+#pragma unroll
+    for (int j = 0; j < C::TPX_; ++j) {
+        const int t = wpx * C::TPX_ + j;
+        const int tr = t / C::TPR, tc = t - tr * C::TPR;
+        const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+        const bool pok = gh < H && gw < W;
+        const long long poff = (long long)gh * W + gw;
+#pragma unroll
+        for (int i = 0; i < C::TCO_; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wco * C::TCO_ + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (pok && co < a.Co) {
+                    float v = acc[i][j][r] * OUT_UNSCALE;
+                    if (a.bias) v += a.bias[co];
+                    if (rb) v += rb[(long long)co * HW + poff];
+                    yb[(long long)co * HW + poff] = v * a.out_scale;
+                }
+            }
+        }
+    }
+}
+
+template <class C>
+int launch_pipe(ConvArgsH a, hipStream_t st) {
+    a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
+    a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
+    dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
+    hipLaunchKernelGGL(conv_f16x2_pipe_kernel<C>, grid, dim3(256), 0, st, a);
+    return lc_launch_status();
+}
+
 template <class C>
 int launch_h(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
@@ -244,19 +500,30 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 3: return launch_h<HCfg<2, 2, 1, 1, 2, 32, KS>>(a, st);   //  64 co x  64 px
         case 4: return launch_h<HCfg<2, 2, 2, 2, 4, 32, KS>>(a, st);   // 128 co x 128 px (4x32)
         case 5: return launch_h<HCfg<1, 4, 2, 1, 2, 64, KS>>(a, st);   //  64 co x 128 px
+        case 12: return launch_pipe<HCfg<1, 4, 2, 2, 4, 64, KS>>(a, st);  // pipelined 64 co x 256 px
+        case 13: return launch_pipe<HCfg<2, 2, 1, 1, 2, 32, KS>>(a, st);  // pipelined 64 co x  64 px
+        case 15: return launch_pipe<HCfg<1, 4, 2, 1, 2, 64, KS>>(a, st);  // pipelined 64 co x 128 px
         default: return LC_EUNSUP;
     }
 }
 
-int auto_cfg_h(int B, int Co, int H, int W) {
-    // Measured on MI355X at batch 8 (profiles/r01_b_conv_sweep_f16x2_b8.txt): the 64co x 256px block
-    // (cfg 2, 62 KB LDS, 2 blocks/CU) is best (213-318 TF effective) whenever it still yields
-    // >= 256 blocks; the 128-co blocks need 90 KB LDS (1 block/CU) and lose; small problems
-    // (L3: 4x128 px) want the 64x64 block (cfg 3) to fill the 256 CUs.
+int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
+    // Measured on MI355X at batch 8 (profiles/r01_c_conv_sweep_f16x2_b8.txt).  Two kernels:
+    //  * conv_f16x2_kernel (cfg 2/5/3): 2 blocks per CU, single LDS buffer -- best for short K
+    //    (Ci <= 128): 200-278 TF effective;
+    //  * conv_f16x2_pipe_kernel (cfg 12/15/13): 1 block per CU, LDS double buffered, prefetch of
+    //    the next K chunk overlapped with the MFMAs -- best for long K (Ci >= 256): 260-310 TF,
+    //    and the only one that keeps the 4x128-pixel level above 200 TF.
     const long long px = (long long)B * H * W;
     auto blocks = [&](int bn, int pxb) { return ((Co + bn - 1) / bn) * ((px + pxb - 1) / pxb); };
-    if (H % 4 == 0 && W % 64 == 0 && blocks(64, 256) >= 256) return 2;
-    if (H % 2 == 0 && W % 64 == 0 && blocks(64, 128) >= 512) return 5;
+    const bool t256 = H % 4 == 0 && W % 64 == 0, t128 = H % 2 == 0 && W % 64 == 0;
+    if (Ci >= 256) {
+        if (ks == 3 && t256 && blocks(64, 256) >= 256) return 12;
+        if (t128 && blocks(64, 128) >= 256) return 15;
+        return 13;
+    }
+    if (t256 && blocks(64, 256) >= 256) return 2;
+    if (t128 && blocks(64, 128) >= 512) return 5;
     return 3;
 }
 
@@ -314,6 +581,6 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.Cib = (Ci + 15) / 16 * 2; a.Cop = (Co + 63) / 64 * 64;
     a.out_scale = out_scale;
     a.tiles_h = a.tiles_w = 0;
-    if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Co, H, W);
+    if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
 }

@@ -30,12 +30,14 @@ def dev():
     (2, 128, 256, 8, 256, 3), (2, 512, 512, 4, 128, 3), (1, 64, 2, 32, 256, 3),
     (2, 42, 64, 8, 64, 3), (1, 512, 256, 4, 128, 1), (2, 48, 144, 1, 8, 3), (3, 16, 32, 2, 16, 3),
 ])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15])
 @pytest.mark.parametrize("prec", ["f32", "f16x2"])
 def test_conv(dev, B, Ci, Co, H, W, ks, cfg, prec):
     from lidarcrafter_amd import ops as K
     from oracle import denoiser as D
 
+    if prec == "f32" and cfg > 5:
+        pytest.skip("pipelined tile configurations exist for the f16x2 kernel only")
     x = seeded_randn(B, Ci, H, W, seed=1)
     w = seeded_randn(Co, Ci, ks, ks, seed=2) / (Ci * ks * ks) ** 0.5
     b = seeded_randn(Co, seed=3)
