@@ -7,7 +7,7 @@ from lidarcrafter_amd import ops as K
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
-CFGS = (1, 2, 3, 4, 5) if PREC == "f32" else (2, 3, 5, 12, 13, 15)
+CFGS = (1, 2, 3, 4, 5) if PREC == "f32" else (2, 5, 12, 15, 13, 22, 23, 25)
 dev = torch.device("cuda:0")
 shapes = [  # Ci, Co, H, W, ks
     (32, 64, 32, 1024, 3), (64, 64, 32, 1024, 3), (64, 128, 32, 1024, 3), (128, 64, 32, 1024, 3),

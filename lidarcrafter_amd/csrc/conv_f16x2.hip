@@ -47,12 +47,13 @@ struct HCfg {
     static constexpr int TPR = TW / 32;
     static constexpr int XR = TH + 2 * HALO;
     static constexpr int XW = TW + 2 * HALO;
+    static constexpr int NT = 64 * WCO * WPX;           // threads per block (4 or 8 waves)
     static constexpr int XU = CB * XR * XW;             // 16-byte x units per plane per chunk
-    static constexpr int NXU = (XU + 255) / 256;
+    static constexpr int NXU = (XU + NT - 1) / NT;
     static constexpr int WU = NTAP * CB * BN;           // 16-byte weight units per plane
-    static constexpr int NWU = (WU + 255) / 256;
+    static constexpr int NWU = (WU + NT - 1) / NT;
     static_assert(NPT * 32 == TH * TW, "tile shape");
-    static_assert(WCO * WPX == 4, "4 waves");
+    static_assert(WCO * WPX == 4 || WCO * WPX == 8, "4 or 8 waves");
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
@@ -261,14 +262,15 @@ __device__ __forceinline__ void split_store(const float (&v)[8], half8* dst_hi, 
 }
 
 template <class C>
-__global__ __launch_bounds__(256, 1) void conv_f16x2_pipe_kernel(ConvArgsH a) {
+__global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(ConvArgsH a) {
     constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
     constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
     constexpr int KS = 2 * HALO + 1;
     // LDS planes are padded to whole 256-thread passes so that every thread always loads and
     // stores (no exec-mask branches inside the K loop: the whole chunk is one basic block and
     // hipcc can interleave ds_write/VALU with the MFMAs and count its vmcnt waits exactly).
-    constexpr int XUP = NXU * 256, WUP = NWU * 256;
+    constexpr int NT = C::NT;
+    constexpr int XUP = NXU * NT, WUP = NWU * NT;
     constexpr int BUF = 2 * XUP + 2 * WUP;             // half8 units per LDS buffer
     __shared__ half8 lds[2 * BUF];
 
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x2_pipe_kernel(ConvArgsH a) {
     unsigned x_voff[NXU];  // byte offset of (channel-block cb, pixel) inside the sample; OOB = pad
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * NT;
         const int cb = e / (XR * XW);
         const int rem = e - cb * (XR * XW);
         const int r = rem / XW, c = rem - r * XW;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void conv_f16x2_pipe_kernel(ConvArgsH a) {
     long long w_idx[NWU];  // unit index of this thread's weight units for chunk 0
 #pragma unroll
     for (int i = 0; i < NWU; ++i) {
-        int e = tid + i * 256;
+        int e = tid + i * NT;
         if (e >= WU) e = WU - 1;                        // padding units duplicate the last one
         const int row = e / BN, cu = e - row * BN;
         const int tap = row / CB, cb = row - tap * CB;
@@ -358,11 +360,11 @@ __global__ __launch_bounds__(256, 1) void conv_f16x2_pipe_kernel(ConvArgsH a) {
         return t > 0 ? t : 0;
     };
     auto store_x = [&](half8* buf, const float (&xr)[NXU][8], int i) {
-        split_store(xr[i], buf + tid + i * 256, buf + XUP + tid + i * 256);
+        split_store(xr[i], buf + tid + i * NT, buf + XUP + tid + i * NT);
     };
     auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
-        buf[2 * XUP + tid + i * 256] = wr[2 * i];
-        buf[2 * XUP + WUP + tid + i * 256] = wr[2 * i + 1];
+        buf[2 * XUP + tid + i * NT] = wr[2 * i];
+        buf[2 * XUP + WUP + tid + i * NT] = wr[2 * i + 1];
     };
     // one chunk of MFMAs from `cur`; the split+store of the NEXT chunk's registers into `nxt`
     // is spread over the taps (same basic block as the MFMAs)
@@ -479,7 +481,7 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
     dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
-    hipLaunchKernelGGL(conv_f16x2_pipe_kernel<C>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(conv_f16x2_pipe_kernel<C>, grid, dim3(C::NT), 0, st, a);
     return lc_launch_status();
 }
 
@@ -503,6 +505,9 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 12: return launch_pipe<HCfg<1, 4, 2, 2, 4, 64, KS>>(a, st);  // pipelined 64 co x 256 px
         case 13: return launch_pipe<HCfg<2, 2, 1, 1, 2, 32, KS>>(a, st);  // pipelined 64 co x  64 px
         case 15: return launch_pipe<HCfg<1, 4, 2, 1, 2, 64, KS>>(a, st);  // pipelined 64 co x 128 px
+        case 22: return launch_pipe<HCfg<1, 8, 2, 1, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px
+        case 23: return launch_pipe<HCfg<2, 4, 1, 2, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px (1x2)
+        case 25: return launch_pipe<HCfg<2, 4, 1, 1, 2, 64, KS>>(a, st);  // 8 waves, 64 co x 128 px
         default: return LC_EUNSUP;
     }
 }
@@ -517,12 +522,16 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     const long long px = (long long)B * H * W;
     auto blocks = [&](int bn, int pxb) { return ((Co + bn - 1) / bn) * ((px + pxb - 1) / pxb); };
     const bool t256 = H % 4 == 0 && W % 64 == 0, t128 = H % 2 == 0 && W % 64 == 0;
-    if (Ci >= 256) {
-        if (ks == 3 && t256 && blocks(64, 256) >= 256) return 12;
-        if (t128 && blocks(64, 128) >= 256) return 15;
+    if (ks == 1) {
+        if (Ci >= 256) return (t128 && blocks(64, 128) >= 256) ? 15 : 13;
+        return (t128 && blocks(64, 128) >= 512) ? 5 : 3;
+    }
+    if (Ci >= 128) {   // 8-wave pipelined blocks: 270-333 TF when >= 1 block per CU exists
+        if (t256 && blocks(64, 256) >= 256) return 23;
+        if (t128 && blocks(64, 128) >= 256) return 25;
         return 13;
     }
-    if (t256 && blocks(64, 256) >= 256) return 2;
+    if (t256 && blocks(64, 256) >= 256 && Ci >= 64) return 2;
     if (t128 && blocks(64, 128) >= 512) return 5;
     return 3;
 }
