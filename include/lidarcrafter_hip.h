@@ -70,7 +70,18 @@ int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int
 int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, const void* wp_lo,
                              const float* bias, const float* res, int64_t res_bs, float* y,
                              int64_t y_bs, int B, int Ci, int Co, int H, int W, int ks,
-                             float out_scale, int tile_cfg /* 0 = auto */, lc_stream_t s);
+                             float out_scale, int tile_cfg /* 0 = auto */,
+                             const float* gn_coeffs /* NULL or [B, gn_cpad, 4] */, int gn_cpad,
+                             int gn_silu, lc_stream_t s);
+/* Fused input normalisation: with gn_coeffs != NULL the kernel applies
+ *   x <- silu?( (x - mu) * A + Bc )       rows (mu, A, Bc, 0) from lc_groupnorm_coeffs
+ * while staging the input tile (the GN -> SiLU -> Conv chain of efficient_unet.py:101-108 and
+ * layout_unet_v1.py:171-175 becomes stats + conv; the normalised tensor never reaches HBM).
+ * gn_cpad = channels per sample in the table, >= Ci rounded up to 16. */
+int lc_groupnorm_coeffs(const float* x, int64_t x_bs, const double* partials, const float* gamma,
+                        const float* beta, const float* scale, const float* shift, int64_t ss_bs,
+                        float* coeffs, int B, int C, int Cpad, int H, int W, int G, float eps,
+                        lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm (+ affine | + AdaGN scale/shift) (+ SiLU):

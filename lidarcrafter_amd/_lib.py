@@ -28,7 +28,9 @@ SIGNATURES = {
     "lc_packed_conv_weight_f16x2_elems": (i64, [i32, i32, i32]),
     "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "lc_conv2d_ring_f16x2_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
-                                       i32, i32, f32, i32, vp]),
+                                       i32, i32, f32, i32, vp, i32, i32, vp]),
+    "lc_groupnorm_coeffs": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32,
+                                  i32, f32, vp]),
     "lc_groupnorm_partials_elems": (i64, [i32, i32, i32, i32, i32]),
     "lc_groupnorm_stats": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
     "lc_groupnorm_apply": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,

@@ -34,7 +34,19 @@ struct ConvArgsH {
     int B, Ci, Co, H, W, Cib, Cop;
     int tiles_h, tiles_w;
     float out_scale;
+    // optional fused GroupNorm(+AdaGN)+SiLU of the INPUT: rows (mu, A, B, 0) per (b, channel),
+    // Cgn channels per sample (>= Ci rounded up to 16, zero rows beyond Ci); NULL = plain input
+    const f32x4* gn;
+    int Cgn, gn_silu;
 };
+
+constexpr int GN_MAX_C = 1024;   // LDS table of fused GroupNorm rows: 16 KB
+
+__device__ __forceinline__ float gn_act(float x, const f32x4 c, int silu) {
+    float y = fmaf(x - c.x, c.y, c.z);
+    if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+    return y;
+}
 
 template <int WCO, int WPX, int TCO, int TPX, int TH, int TW, int KS>
 struct HCfg {
@@ -73,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
     constexpr int KS = 2 * HALO + 1;
     __shared__ half8 lds[2 * XU + 2 * WU];
+    __shared__ f32x4 ctab[GN_MAX_C];   // fused input GroupNorm rows (mu, A, B, 0) of sample b
     half8* xh = lds;
     half8* xl = lds + XU;
     half8* wh = lds + 2 * XU;
@@ -131,11 +144,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
             }
         }
     };
+    int cur_c0 = 0;   // first channel of the chunk held in xr
     auto store_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < NXU; ++i) {
             const int e = tid + i * 256;
             if (e < XU) {
+                if (a.gn && x_off[i] >= 0) {   // padding stays exactly 0 (the reference pads
+                                               // AFTER the activation); tails have zero rows
+                    const f32x4* g = ctab + cur_c0 + 8 * (x_off[i] >> 24);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu);
+                }
                 half8 hi, lo;
                 split8(xr[i], hi, lo);
                 xh[e] = hi;
@@ -168,10 +188,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
 
     const int nchunk = a.Cib / CB;
+    if (a.gn) {
+        const f32x4* g = a.gn + (long long)b * a.Cgn;
+        for (int i = tid; i < a.Cgn; i += 256) ctab[i] = g[i];
+        __syncthreads();
+    }
     load_chunk(0);
     store_chunk();
     __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
+        cur_c0 = (ch + 1) * 8 * CB;
         if (ch + 1 < nchunk) load_chunk((ch + 1) * 8 * CB);
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
@@ -266,13 +292,13 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
     constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
     constexpr int KS = 2 * HALO + 1;
-    // LDS planes are padded to whole 256-thread passes so that every thread always loads and
-    // stores (no exec-mask branches inside the K loop: the whole chunk is one basic block and
-    // hipcc can interleave ds_write/VALU with the MFMAs and count its vmcnt waits exactly).
     constexpr int NT = C::NT;
-    constexpr int XUP = NXU * NT, WUP = NWU * NT;
+    // every thread always loads NXU / NWU units (no exec-mask branches inside the K loop: a whole
+    // chunk is one basic block); units past the end of a plane are stored to one dummy slot.
+    constexpr int XUP = XU + 1, WUP = WU + 1;
     constexpr int BUF = 2 * XUP + 2 * WUP;             // half8 units per LDS buffer
     __shared__ half8 lds[2 * BUF];
+    __shared__ f32x4 ctab[GN_MAX_C];                   // fused input GroupNorm rows of sample b
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -315,6 +341,17 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     }
     const long long w_chunk = (long long)CB * a.Cop;    // unit stride between K chunks
 
+    const bool use_gn = a.gn != nullptr;
+    if (use_gn) {
+        const f32x4* g = a.gn + (long long)b * a.Cgn;
+        for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
+    }
+    int x_cb8[NXU];        // 8 * channel-block of the unit, or -1 for padding units
+#pragma unroll
+    for (int i = 0; i < NXU; ++i) {
+        const int e = tid + i * NT;
+        x_cb8[i] = x_voff[i] == 0xFFFFFFF0u ? -1 : 8 * (e / (XR * XW));
+    }
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
         for (int i = 0; i < NXU; ++i)
@@ -359,17 +396,28 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         const int t = NTAP - 1 - (NWU - 1 - i) / 2;
         return t > 0 ? t : 0;
     };
-    auto store_x = [&](half8* buf, const float (&xr)[NXU][8], int i) {
-        split_store(xr[i], buf + tid + i * NT, buf + XUP + tid + i * NT);
+    auto store_x = [&](half8* buf, float (&xr)[NXU][8], int i, int ch) {
+        const int e = tid + i * NT;
+        const int d = e < XU ? e : XU;                  // dummy slot for the padding units
+        if (use_gn) {   // fused GroupNorm(+AdaGN)+SiLU of the input; padding units stay exactly 0
+            const int cb8 = x_cb8[i];
+            const f32x4* g = ctab + ch * 16 + (cb8 < 0 ? 0 : cb8);
+            const float keep = cb8 < 0 ? 0.0f : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu) * keep;
+        }
+        split_store(xr[i], buf + d, buf + XUP + d);
     };
     auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
-        buf[2 * XUP + tid + i * NT] = wr[2 * i];
-        buf[2 * XUP + WUP + tid + i * NT] = wr[2 * i + 1];
+        const int e = tid + i * NT;
+        const int d = e < WU ? e : WU;
+        buf[2 * XUP + d] = wr[2 * i];
+        buf[2 * XUP + WUP + d] = wr[2 * i + 1];
     };
     // one chunk of MFMAs from `cur`; the split+store of the NEXT chunk's registers into `nxt`
     // is spread over the taps (same basic block as the MFMAs)
-    auto compute = [&](const half8* cur, half8* nxt, const float (&xr)[NXU][8],
-                       const half8 (&wr)[2 * NWU]) {
+    auto compute = [&](const half8* cur, half8* nxt, float (&xr)[NXU][8],
+                       const half8 (&wr)[2 * NWU], int chn) {
         const half8* cxh = cur;
         const half8* cxl = cur + XUP;
         const half8* cwh = cur + 2 * XUP;
@@ -402,7 +450,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
             // hipcc schedule each tap region on its own.)
 #pragma unroll
             for (int i = 0; i < NXU; ++i)
-                if (tap == store_tap_x(i)) store_x(nxt, xr, i);
+                if (tap == store_tap_x(i)) store_x(nxt, xr, i, chn);
 #pragma unroll
             for (int i = 0; i < NWU; ++i)
                 if (tap == store_tap_w(i)) store_w(nxt, wr, i);
@@ -434,8 +482,9 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     // prologue: chunk 0 -> cur
     load_x(xr, 0);
     load_w(wr, 0);
+    if (use_gn) __syncthreads();                        // ctab visible
 #pragma unroll
-    for (int i = 0; i < NXU; ++i) store_x(cur, xr, i);
+    for (int i = 0; i < NXU; ++i) store_x(cur, xr, i, 0);
 #pragma unroll
     for (int i = 0; i < NWU; ++i) store_w(cur, wr, i);
     __syncthreads();
@@ -446,7 +495,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         load_w(wr, min(ch + 1, last));
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc would
                                              // otherwise sink every load next to its use)
-        compute(cur, nxt, xr, wr);
+        compute(cur, nxt, xr, wr, min(ch + 1, last));
         __syncthreads();
         half8* t = cur; cur = nxt; nxt = t;
     }
@@ -578,6 +627,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
                                         const void* wp_lo, const float* bias, const float* res,
                                         int64_t res_bs, float* y, int64_t y_bs, int B, int Ci,
                                         int Co, int H, int W, int ks, float out_scale, int tile_cfg,
+                                        const float* gn_coeffs, int gn_cpad, int gn_silu,
                                         lc_stream_t s) {
     if (!x || !wp_hi || !wp_lo || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0)
         return LC_EINVAL;
@@ -590,6 +640,9 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.Cib = (Ci + 15) / 16 * 2; a.Cop = (Co + 63) / 64 * 64;
     a.out_scale = out_scale;
     a.tiles_h = a.tiles_w = 0;
+    a.gn = reinterpret_cast<const f32x4*>(gn_coeffs);
+    a.Cgn = gn_cpad; a.gn_silu = gn_silu;
+    if (gn_coeffs && (gn_cpad < (Ci + 15) / 16 * 16 || gn_cpad > GN_MAX_C)) return LC_EINVAL;
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
 }

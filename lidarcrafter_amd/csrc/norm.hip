@@ -92,7 +92,53 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     }
 }
 
+// Per-(b, channel) affine form of GroupNorm(+AdaGN): y = (x - mu) * A + Bc, stored as float4
+// (mu, A, Bc, 0) rows so a consumer (the conv staging pass) can apply GN + SiLU on the fly and the
+// normalised tensor never exists in HBM.
+__global__ void gn_coeffs_kernel(const double* __restrict__ part, const float* __restrict__ x,
+                                 long long x_bs, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, long long ss_bs,
+                                 f32x4* __restrict__ out, int B, int C, int Cpad, int G,
+                                 long long HW, int nch, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Cpad) return;
+    const int b = i / Cpad, c = i - b * Cpad;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const int cpg = C / G, g = c / cpg;
+        const double* pp = part + ((long long)b * G + g) * nch * 2;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nch; ++k) { s += pp[2 * k]; q += pp[2 * k + 1]; }
+        const double n = (double)cpg * (double)HW;
+        const double dm = s / n;
+        double var = q / n - dm * dm;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+        const float sh = shift ? shift[b * ss_bs + c] : 0.0f;
+        r.x = mu; r.y = rstd * ga * sc; r.z = be * sc + sh;
+    }
+    out[i] = r;
+}
+
 }  // namespace
+
+extern "C" int lc_groupnorm_coeffs(const float* x, int64_t x_bs, const double* partials,
+                                   const float* gamma, const float* beta, const float* scale,
+                                   const float* shift, int64_t ss_bs, float* coeffs, int B, int C,
+                                   int Cpad, int H, int W, int G, float eps, lc_stream_t s) {
+    if (!x || !partials || !coeffs || B <= 0 || G <= 0 || C % G || Cpad < C) return LC_EINVAL;
+    const long long HW = (long long)H * W;
+    const int nch = gn_chunks((long long)(C / G) * HW);
+    const int n = B * Cpad;
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3((n + 255) / 256), dim3(256), 0, lc_s(s), partials, x,
+                       (long long)x_bs, gamma, beta, scale, shift, (long long)ss_bs,
+                       reinterpret_cast<f32x4*>(coeffs), B, C, Cpad, G, HW, nch, eps);
+    return lc_launch_status();
+}
 
 extern "C" int64_t lc_groupnorm_partials_elems(int B, int C, int H, int W, int G) {
     if (G <= 0 || C % G) return 0;

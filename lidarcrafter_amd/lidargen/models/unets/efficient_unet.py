@@ -59,10 +59,13 @@ class SelfAttentionBlock(nn.Module):
     def forward(self, x, out=None):
         B, C, H, W = x.shape
         heads = self.attn.num_heads
-        h = self.norm(x)
-        # in_proj on channel-major tokens == 1x1 conv on NCHW
-        qkv = K.conv2d_ring(h, self._pk_in, self.attn.in_proj_weight[:, :, None, None],
-                            self.attn.in_proj_bias)
+        # in_proj on channel-major tokens == 1x1 conv on NCHW (GroupNorm fused into its staging)
+        w_in = self.attn.in_proj_weight[:, :, None, None]
+        if K.fuse_gn(3 * C):
+            qkv = K.conv2d_ring(x, self._pk_in, w_in, self.attn.in_proj_bias,
+                                gn_coeffs=self.norm.coeffs(x), gn_silu=False)
+        else:
+            qkv = K.conv2d_ring(self.norm(x), self._pk_in, w_in, self.attn.in_proj_bias)
         t = qkv.view(B, 3 * C, H * W)
         o = K.attention_cm(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], heads,
                            scale=1.0 / float(np.sqrt(C // heads)))
@@ -94,6 +97,15 @@ class ResidualBlock(nn.Module):
         self._scale_f = float(scale)
 
     def forward(self, x, emb=None, scale_shift=None, out=None):
+        if K.fuse_gn(self.conv1.out_channels):   # GN -> SiLU -> conv: stats pass + conv only
+            h = self.conv1(x, gn_coeffs=self.norm1.coeffs(x))
+            c2 = (self.norm2.coeffs(h, emb, scale_shift=scale_shift) if self.has_emb
+                  else self.norm2.coeffs(h))
+            if isinstance(self.skip, nn.Identity):
+                sk = x
+            else:
+                sk = self.skip(x)
+            return self.conv2(h, res=sk, out=out, out_scale=self._scale_f, gn_coeffs=c2)
         a = self.norm1(x, act_silu=True)
         h = self.conv1(a)
         if self.has_emb:

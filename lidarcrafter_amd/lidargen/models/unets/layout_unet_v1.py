@@ -25,7 +25,7 @@ import torch.nn as nn
 from lidarcrafter_amd import ops as K
 
 from . import encoding, ops
-from .nn import SiLU, conv_nd, conv_nd_range, linear, normalization, zero_module
+from .nn import SiLU, conv_nd, conv_nd_range, gn32_coeffs, linear, normalization, zero_module
 
 
 class TimestepBlock(nn.Module):
@@ -71,13 +71,24 @@ class ResBlock(TimestepBlock):
         return ss[:, :C], ss[:, C:]
 
     def forward(self, x, emb=None, scale_shift=None, out=None):
-        a = self.in_layers[0](x, act_silu=True)
-        if self.updown:
-            a, x = self.op(a), self.op(x)
-        h = self.in_layers[2](a)
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
+        fuse = K.fuse_gn(self.out_channels)
+        if self.updown:      # GN -> SiLU -> resample -> conv: the norm cannot ride on the conv
+            a = self.op(self.in_layers[0](x, act_silu=True))
+            x = self.op(x)
+            h = self.in_layers[2](a)
+        elif fuse:
+            a = None
+            h = self.in_layers[2](x, gn_coeffs=gn32_coeffs(self.in_layers[0], x))
+        else:
+            a = self.in_layers[0](x, act_silu=True)
+            h = self.in_layers[2](a)
+        if fuse:
+            sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
+            return self.out_layers[3](h, res=sk, out=out,
+                                      gn_coeffs=gn32_coeffs(self.out_layers[0], h, scale, shift))
         a2 = self.out_layers[0](h, scale, shift, act_silu=True,
-                                out=a if a.shape == h.shape else None)
+                                out=a if a is not None and a.shape == h.shape else None)
         sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
         return self.out_layers[3](a2, res=sk, out=out)
 
@@ -136,7 +147,10 @@ class ObjectAwareCrossAttention(nn.Module):
         L1 = H * W
         xs = x.reshape(B, C, L1) if x.is_contiguous() else x.contiguous().view(B, C, L1)
         pos_img, pos_lay, k_lay, v_lay = self.condition_operands(cond_kwargs)
-        qkv = self.qkv_projector(self.norm_for_qkv(xs))
+        if K.fuse_gn(3 * C):
+            qkv = self.qkv_projector(xs, gn_coeffs=gn32_coeffs(self.norm_for_qkv, xs))
+        else:
+            qkv = self.qkv_projector(self.norm_for_qkv(xs))
         heads = self.num_heads
         scale = 1.0 / math.sqrt(2 * C // heads)   # (q*s)(k*s) with s = (2C/h)^-1/4, :489-492
         a = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale,
@@ -357,5 +371,6 @@ class LayoutUnetV1(nn.Module):
             else:
                 dst = None
             h, _ = blk(cats[j], emb, lay, scale_shifts=ssi, out=dst)
-        a = self.out[0](h, act_silu=True)
-        return self.out[2](a)
+        if K.fuse_gn(self.out_channels):
+            return self.out[2](h, gn_coeffs=gn32_coeffs(self.out[0], h))
+        return self.out[2](self.out[0](h, act_silu=True))

@@ -31,6 +31,14 @@ class GroupNorm32(nn.GroupNorm):
                            act_silu=act_silu, out=out)
 
 
+def gn32_coeffs(norm: "GroupNorm32", x, scale=None, shift=None):
+    """Statistics pass of a GroupNorm32 on [B,C,H,W] / [B,C,L] -> rows for the fused conv input."""
+    if x.dim() == 3:
+        B, C, L = x.shape
+        x = x.reshape(B, C, 1, L)
+    return K.groupnorm_coeffs(x, norm.num_groups, norm.eps, norm.weight, norm.bias, scale, shift)
+
+
 class PointwiseConv1d(nn.Conv1d):
     """nn.Conv1d(kernel_size=1) parameters ([Co, Ci, 1]) driven through the 1x1 MFMA conv."""
 
@@ -39,12 +47,12 @@ class PointwiseConv1d(nn.Conv1d):
         super().__init__(in_channels, out_channels, 1)
         self._packed = K.PackedConv()
 
-    def forward(self, x, res=None, out=None):
+    def forward(self, x, res=None, out=None, gn_coeffs=None, gn_silu=False):
         B, C, L = x.shape
         r4 = None if res is None else res.reshape(B, -1, 1, L)
         o4 = None if out is None else out.view(B, -1, 1, L)
         y = K.conv2d_ring(x.reshape(B, C, 1, L), self._packed, self.weight, self.bias, res=r4,
-                          out=o4)
+                          out=o4, gn_coeffs=gn_coeffs, gn_silu=gn_silu)
         return y.view(B, -1, L)
 
 

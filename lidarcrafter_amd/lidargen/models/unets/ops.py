@@ -62,9 +62,10 @@ class Conv2d(nn.Conv2d):
         self.ring = ring
         self._packed = K.PackedConv()
 
-    def forward(self, x, res=None, out=None, out_scale: float = 1.0):
+    def forward(self, x, res=None, out=None, out_scale: float = 1.0, gn_coeffs=None,
+                gn_silu: bool = True):
         return K.conv2d_ring(x, self._packed, self.weight, self.bias, res=res, out=out,
-                             out_scale=out_scale)
+                             out_scale=out_scale, gn_coeffs=gn_coeffs, gn_silu=gn_silu)
 
 
 class Resample(nn.Module):
@@ -96,6 +97,10 @@ class GroupNorm(nn.GroupNorm):
         return K.groupnorm(x, self.num_groups, self.eps, self.weight, self.bias,
                            act_silu=act_silu, out=out)
 
+    def coeffs(self, x):
+        """Statistics only: per-(b, channel) rows the next conv applies while staging its input."""
+        return K.groupnorm_coeffs(x, self.num_groups, self.eps, self.weight, self.bias)
+
 
 class AdaGN(nn.GroupNorm):
     def __init__(self, emb_channels, out_channels, num_groups, eps=1e-5):
@@ -112,6 +117,10 @@ class AdaGN(nn.GroupNorm):
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
         return K.groupnorm(x, self.num_groups, self.eps, None, None, scale, shift,
                            act_silu=act_silu, out=out)
+
+    def coeffs(self, x, emb=None, scale_shift=None):
+        scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
+        return K.groupnorm_coeffs(x, self.num_groups, self.eps, None, None, scale, shift)
 
 
 class ConditionalSequential(nn.Sequential):

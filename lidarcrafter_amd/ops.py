@@ -81,6 +81,21 @@ import os as _os
 CONV_PRECISION = _os.environ.get("LC_CONV_PRECISION", "f16x2")
 
 
+# Fuse GroupNorm(+AdaGN)+SiLU into the consuming convolution's staging pass (f16x2 kernels):
+# the normalised/activated tensor is never written to HBM (saves one read + one write per GN).
+FUSE_GN = _os.environ.get("LC_FUSE_GN", "1") != "0"
+
+
+def fuse_gn(out_channels: int = 0) -> bool:
+    """Fuse only where it pays (devtools/gn_fuse_sweep.py on MI355X): every 64-output-channel
+    block of the conv re-applies the activation to its input tile, so the fused form wins for
+    Co <= 64 (-4...-9 %) and loses for wider layers (+2...+16 %)."""
+    return FUSE_GN and CONV_PRECISION == "f16x2" and out_channels <= FUSE_GN_MAX_CO
+
+
+FUSE_GN_MAX_CO = int(_os.environ.get("LC_FUSE_GN_MAX_CO", "64"))
+
+
 def set_conv_precision(mode: str) -> str:
     global CONV_PRECISION
     if mode not in ("f32", "f16x2"):
@@ -137,10 +152,15 @@ class PackedConv:
 def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, out_scale: float = 1.0,
-                tile_cfg: int = 0, precision: Optional[str] = None) -> torch.Tensor:
-    """y = (conv_ring(x, W) + bias [+ res]) * out_scale.  ops.py:149-173 of the reference."""
+                tile_cfg: int = 0, precision: Optional[str] = None,
+                gn_coeffs: Optional[torch.Tensor] = None, gn_silu: bool = True) -> torch.Tensor:
+    """y = (conv_ring(x', W) + bias [+ res]) * out_scale with x' = x, or -- when `gn_coeffs`
+    (from `groupnorm_coeffs`) is given -- x' = silu?(GroupNorm(x)) applied on the fly while the
+    input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference."""
     x_bs = _bs4(x, "x")
     prec = precision or CONV_PRECISION
+    if gn_coeffs is not None and prec != "f16x2":
+        raise ValueError("fused input GroupNorm exists for the f16x2 conv kernels only")
     if prec == "f16x2":
         wh, wl = packed.get_f16x2(weight)
     else:
@@ -164,10 +184,18 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     ks = packed.ks
     with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks):
         if prec == "f16x2":
+            cpad = 0
+            if gn_coeffs is not None:
+                _req(gn_coeffs, "gn_coeffs")
+                if gn_coeffs.dim() != 3 or gn_coeffs.shape[0] != B or gn_coeffs.shape[2] != 4 or \
+                        not gn_coeffs.is_contiguous():
+                    raise ValueError("gn_coeffs must be contiguous [B, Cpad, 4]")
+                cpad = gn_coeffs.shape[1]
             check(lib().lc_conv2d_ring_f16x2_fwd(x.data_ptr(), x_bs, wh.data_ptr(), wl.data_ptr(),
                                                  _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                  Ci, Co, H, W, ks, float(out_scale),
-                                                 int(tile_cfg), _stream()),
+                                                 int(tile_cfg), _p(gn_coeffs), cpad, int(gn_silu),
+                                                 _stream()),
                   "lc_conv2d_ring_f16x2_fwd")
         else:
             check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res),
@@ -217,6 +245,35 @@ def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=
         check(lib().lc_groupnorm_apply(x.data_ptr(), x_bs, part.data_ptr(), _p(gamma), _p(beta),
                                        _p(scale), _p(shift), ss_bs, out.data_ptr(), y_bs, B, C, H,
                                        W, G, float(eps), int(act_silu), st), "lc_groupnorm_apply")
+    return out
+
+
+def groupnorm_coeffs(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=None,
+                     shift=None) -> torch.Tensor:
+    """Statistics pass only: returns the per-(b, channel) rows (mu, A, Bc, 0) [B, C^16, 4] that
+    `conv2d_ring(..., gn_coeffs=...)` applies while staging its input."""
+    x_bs = _bs4(x, "x")
+    B, C, H, W = x.shape
+    if C % G:
+        raise ValueError(f"groupnorm: C={C} not divisible by G={G}")
+    ss_bs = 0
+    if scale is not None:
+        _req(scale, "scale"), _req(shift, "shift")
+        if scale.shape != (B, C) or shift.shape != (B, C) or scale.stride(1) != 1 or \
+                shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+            raise ValueError("groupnorm: scale/shift must be [B,C] with unit inner stride")
+        ss_bs = scale.stride(0)
+    cpad = (C + 15) // 16 * 16
+    out = torch.empty((B, cpad, 4), device=x.device, dtype=_F32)
+    n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
+    part = _partials(x.device, n)
+    st = _stream()
+    with _Timed("groupnorm", 4.0 * B * C * H * W):
+        check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, st),
+              "lc_groupnorm_stats")
+        check(lib().lc_groupnorm_coeffs(x.data_ptr(), x_bs, part.data_ptr(), _p(gamma), _p(beta),
+                                        _p(scale), _p(shift), ss_bs, out.data_ptr(), B, C, cpad,
+                                        H, W, G, float(eps), st), "lc_groupnorm_coeffs")
     return out
 
 

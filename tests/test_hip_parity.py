@@ -65,6 +65,35 @@ def test_conv_f16x2_accuracy_vs_fp64(dev):
         assert e16 < 2e-6 and e32 < 1e-6, (xs, ws, e16, e32)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks,G", [(2, 64, 64, 8, 128, 3, 8), (1, 256, 128, 8, 256, 3, 32),
+                                              (2, 48, 32, 4, 64, 3, 8), (2, 512, 96, 4, 128, 1, 32),
+                                              (1, 128, 64, 32, 1024, 3, 8)])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25])
+def test_conv_fused_groupnorm(dev, B, Ci, Co, H, W, ks, G, cfg):
+    """GN(+AdaGN scale/shift)+SiLU applied inside the conv staging == GN kernel then conv."""
+    from lidarcrafter_amd import ops as K
+    from oracle import denoiser as D
+
+    x = seeded_randn(B, Ci, H, W, seed=50) * 1.3 + 0.4
+    w = seeded_randn(Co, Ci, ks, ks, seed=51) / (Ci * ks * ks) ** 0.5
+    bias = seeded_randn(Co, seed=52)
+    ga, be = 1 + 0.1 * seeded_randn(Ci, seed=53), 0.1 * seeded_randn(Ci, seed=54)
+    ss = 0.3 * seeded_randn(B, 2 * Ci, seed=55)
+    a = D.silu(D.group_norm(x, G, ga, be, 1e-6) * (1 + ss[:, :Ci, None, None]) + ss[:, Ci:, None, None])
+    ref = D.conv_ring(a, w, bias)
+    ssd = ss.to(dev)
+    co = K.groupnorm_coeffs(x.to(dev), G, 1e-6, ga.to(dev), be.to(dev), ssd[:, :Ci], ssd[:, Ci:])
+    y = K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev), bias.to(dev), tile_cfg=cfg,
+                      precision="f16x2", gn_coeffs=co, gn_silu=True)
+    assert rel_l2(y, ref) < 3e-6, rel_l2(y, ref)
+    # no activation (attention qkv projection): GN only
+    ref2 = D.conv_ring(D.group_norm(x, G, ga, be, 1e-6), w, bias)
+    co2 = K.groupnorm_coeffs(x.to(dev), G, 1e-6, ga.to(dev), be.to(dev))
+    y2 = K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev), bias.to(dev), tile_cfg=cfg,
+                       precision="f16x2", gn_coeffs=co2, gn_silu=False)
+    assert rel_l2(y2, ref2) < 3e-6, rel_l2(y2, ref2)
+
+
 def test_conv_strided_views(dev):
     """Producer writes into a channel slice of a concat buffer; consumer reads a slice."""
     from lidarcrafter_amd import ops as K
