@@ -84,16 +84,21 @@ def cpu_baseline(n_steps: int = 2):
 
 
 def main():
+    global BATCH_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU,
+                    help="samples per GPU (default 8 = the C2 workload; other values are "
+                         "diagnostic and are named in config.workload)")
     ap.add_argument("--conv-precision", choices=["f32", "f16x2"], default=None,
                     help="override LC_CONV_PRECISION (default f16x2)")
     args = ap.parse_args()
 
+    BATCH_PER_GPU = args.batch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -188,14 +193,15 @@ def main():
         line = {
             "metric": "denoising-steps/sec, nuScenes 32x1024 range image",
             "value": round(steps_per_s, 3),
-            "unit": "denoising-steps/s (each step = batch of 8 frames per GPU)",
+            "unit": f"denoising-steps/s (each step = batch of {BATCH_PER_GPU} frames per GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f16x2-split MFMA, fp32 accumulate (fp32-class accuracy)"
                       if K.CONV_PRECISION == "f16x2" else "f32"), "data": "synthetic",
-            "config": {"workload": "C2: EfficientUNet nuscenes-unet-uncond (31.1M params, seeded "
-                                   "random init), 32x1024, DDIM eta=0, batch 8 per GPU, "
+            "config": {"workload": ("C2" if BATCH_PER_GPU == 8 else f"C2-shape at batch {BATCH_PER_GPU}") +
+                                   ": EfficientUNet nuscenes-unet-uncond (31.1M params, seeded "
+                                   f"random init), 32x1024, DDIM eta=0, batch {BATCH_PER_GPU} per GPU, "
                                    f"{total}-step schedule ({args.warmup} warmup + {args.steps} timed)",
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
                        "resolution": list(RES), "parallelism": f"dp{world} (no data-path collective)",
