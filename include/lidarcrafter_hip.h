@@ -190,6 +190,26 @@ int lc_points_in_boxes_mask(const float* boxes, int n_boxes, const float* pts, i
 int lc_points_in_boxes_index(const float* boxes, const float* pts, int B, int n_boxes, int n_pts,
                              float margin, int32_t* out_idx, lc_stream_t s);
 
+/* ---------------------------------------------------------------------------------------------
+ * RoI-aware voxel pooling of point features: lidargen/ops/roiaware_pool3d/
+ *   roiaware_pool3d_utils.py:55-107 (RoIAwarePool3dFunction) -> src/roiaware_pool3d.cpp:30-117
+ *   (pybind forward / backward :173-174) -> src/roiaware_pool3d_kernel.cu:39-310.
+ * rois [N,7], pts [P,3], pts_feature [P,C] -> pooled [N,X,Y,Z,C] (must be zero-filled by the
+ * caller like the reference's new_zeros), pts_idx_of_voxels int32 [N,X,Y,Z,max_pts] (slot 0 =
+ * count), argmax int32 [N,X,Y,Z,C] (max pooling).  pts_mask_scratch: int32 [N,P].
+ * pool_method: 0 max, 1 avg.  Backward accumulates into grad_in [P,C] (zero-filled by the caller)
+ * with atomicAdd, like the reference.
+ * ------------------------------------------------------------------------------------------- */
+int lc_roiaware_pool3d_fwd(const float* rois, const float* pts, const float* pts_feature,
+                           int n_boxes, int n_pts, int channels, int out_x, int out_y, int out_z,
+                           int max_pts_each_voxel, int pool_method, int32_t* pts_mask_scratch,
+                           int32_t* pts_idx_of_voxels, int32_t* argmax, float* pooled,
+                           lc_stream_t s);
+int lc_roiaware_pool3d_bwd(const int32_t* pts_idx_of_voxels, const int32_t* argmax,
+                           const float* grad_out, float* grad_in, int n_boxes, int channels,
+                           int out_x, int out_y, int out_z, int max_pts_each_voxel,
+                           int pool_method, lc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

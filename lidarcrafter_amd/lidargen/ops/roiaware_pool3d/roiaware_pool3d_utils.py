@@ -2,8 +2,8 @@
 lidargen/ops/roiaware_pool3d/roiaware_pool3d_utils.py:9-45 on the HIP kernels
 (lc_points_in_boxes_mask / _index).  The reference's `points_in_boxes_cpu` runs a C++ double loop
 on the host (called >= 2x per frame in the temporal loop); here both entry points
-run on the GPU.  RoIAwarePool3d (voxel pooling, :48-107) is not called by any generation script
-and is not built yet."""
+run on the GPU.  RoIAwarePool3d (voxel pooling, :48-107; not called by any generation script) runs
+on lc_roiaware_pool3d_fwd/_bwd."""
 from __future__ import annotations
 
 import numpy as np
@@ -49,5 +49,35 @@ def points_in_boxes_gpu(points, boxes):
 class RoIAwarePool3d(torch.nn.Module):
     def __init__(self, out_size, max_pts_each_voxel=128):
         super().__init__()
-        raise NotImplementedError("RoIAwarePool3d: not on the generation path (SURVEY.md §8a-20); "
-                                  "voxel-pool kernels are a later row")
+        self.out_size = out_size
+        self.max_pts_each_voxel = max_pts_each_voxel
+
+    def forward(self, rois, pts, pts_feature, pool_method="max"):
+        assert pool_method in ["max", "avg"]
+        return RoIAwarePool3dFunction.apply(rois, pts, pts_feature, self.out_size,
+                                            self.max_pts_each_voxel, pool_method)
+
+
+class RoIAwarePool3dFunction(torch.autograd.Function):
+    """rois (N,7), pts (P,3), pts_feature (P,C) -> pooled (N, X, Y, Z, C); reference
+    roiaware_pool3d_utils.py:55-107 (forward + atomicAdd backward) on lc_roiaware_pool3d_*."""
+
+    @staticmethod
+    def forward(ctx, rois, pts, pts_feature, out_size, max_pts_each_voxel, pool_method):
+        assert rois.shape[1] == 7 and pts.shape[1] == 3
+        if isinstance(out_size, int):
+            out_size = (out_size,) * 3
+        else:
+            assert len(out_size) == 3 and all(isinstance(k, int) for k in out_size)
+        method = {"max": 0, "avg": 1}[pool_method]
+        pooled, vox, argmax = K.roiaware_pool3d_forward(rois.float(), pts.float(),
+                                                        pts_feature.float(), tuple(out_size),
+                                                        max_pts_each_voxel, method)
+        ctx.roiaware_pool3d_for_backward = (vox, argmax, method, pts.shape[0])
+        return pooled
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        vox, argmax, method, num_pts = ctx.roiaware_pool3d_for_backward
+        grad_in = K.roiaware_pool3d_backward(vox, argmax, grad_out.float(), num_pts, method)
+        return None, None, grad_in, None, None, None

@@ -435,3 +435,33 @@ def points_in_boxes_index(points: torch.Tensor, boxes: torch.Tensor, margin: flo
                                          float(margin), out.data_ptr(), _stream()),
           "lc_points_in_boxes_index")
     return out
+
+
+def roiaware_pool3d_forward(rois, pts, pts_feature, out_size, max_pts_each_voxel: int, method: int):
+    """-> (pooled [N,X,Y,Z,C], pts_idx_of_voxels int32 [N,X,Y,Z,max_pts], argmax int32 [N,X,Y,Z,C])."""
+    for n_, t_ in (("rois", rois), ("pts", pts), ("pts_feature", pts_feature)):
+        _req(t_, n_)
+    rois, pts, pts_feature = rois.contiguous(), pts.contiguous(), pts_feature.contiguous()
+    ox, oy, oz = out_size
+    N, P, C = rois.shape[0], pts.shape[0], pts_feature.shape[1]
+    dev = rois.device
+    pooled = torch.zeros((N, ox, oy, oz, C), device=dev, dtype=_F32)
+    argmax = torch.zeros((N, ox, oy, oz, C), device=dev, dtype=torch.int32)
+    vox = torch.zeros((N, ox, oy, oz, max_pts_each_voxel), device=dev, dtype=torch.int32)
+    scratch = torch.empty((N, P), device=dev, dtype=torch.int32)
+    check(lib().lc_roiaware_pool3d_fwd(rois.data_ptr(), pts.data_ptr(), pts_feature.data_ptr(), N,
+                                       P, C, ox, oy, oz, max_pts_each_voxel, method,
+                                       scratch.data_ptr(), vox.data_ptr(), argmax.data_ptr(),
+                                       pooled.data_ptr(), _stream()), "lc_roiaware_pool3d_fwd")
+    return pooled, vox, argmax
+
+
+def roiaware_pool3d_backward(vox, argmax, grad_out, num_pts: int, method: int) -> torch.Tensor:
+    _req(grad_out, "grad_out")
+    grad_out = grad_out.contiguous()
+    N, ox, oy, oz, C = grad_out.shape
+    grad_in = torch.zeros((num_pts, C), device=grad_out.device, dtype=_F32)
+    check(lib().lc_roiaware_pool3d_bwd(vox.data_ptr(), argmax.data_ptr(), grad_out.data_ptr(),
+                                       grad_in.data_ptr(), N, C, ox, oy, oz, vox.shape[-1], method,
+                                       _stream()), "lc_roiaware_pool3d_bwd")
+    return grad_in

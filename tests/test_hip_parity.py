@@ -472,3 +472,88 @@ def test_load_points_as_images_api(dev, golden):
     img = load_points_as_images(points=pts, scan_unfolding=False, H=16, W=256)
     ref, _ = L.load_points_as_images(pts, 16, 256, mode="f32")
     assert isinstance(img, np.ndarray) and np.array_equal(img, ref)
+
+
+# ------------------------------------------------------------------------------------- other configs
+def test_unet_64x2048(dev):
+    """C4 resolution: the same denoiser at 64x2048 (H, W are parameters of every kernel)."""
+    from oracle import denoiser as D
+
+    m = _uncond(32, (64, 2048), dev)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = seeded_randn(1, 2, 64, 2048, seed=60)
+    lam = torch.tensor([0.7])
+    with torch.no_grad():
+        y = m(x.to(dev), lam.to(dev))
+    r = rel_l2(y, D.efficient_unet_forward(sd, x, lam))
+    assert r < 2e-5, r
+
+
+def test_autoregressive_cond_config(dev):
+    """nuscenes-auto-reg-v2 shapes (11 condition channels = concat_cond 10 + autoregressive 1),
+    reduced width, DDPM mode like sample_and_save_temporal.py:189, vs the oracle sampler."""
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from oracle import denoiser as D
+    from oracle import diffusion as DF
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    m, enc = build_cond_pair((8, 64), 8, 32, cond_out=11)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sde = {k: v.clone() for k, v in enc.state_dict().items()}
+    batch = synth_layout_batch(2, 8, 64, seed=61, n_extra=1)
+    ddpm = CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval().to(dev)
+    assert ddpm.sampling_shape == (2, 8, 64)
+    rng = [torch.Generator().manual_seed(70 + i) for i in range(2)]
+    xs = ddpm.sample({k: v.to(dev) for k, v in batch.items()}, 2, 4, progress=False, rng=rng,
+                     return_all=True, mode="ddpm").cpu()
+    cond = D.layout_encoder_forward(sde, batch, feature_map_size=[8, 64],
+                                    resolution_to_attention=[4, 8])
+    den = lambda x, lam: D.layout_unet_v1_forward(sd, x, lam, cond, image_size=8, model_channels=32)
+    rng = [torch.Generator().manual_seed(70 + i) for i in range(2)]
+    ref = DF.sample(den, (2, 2, 8, 64), 4, rng, mode="ddpm", return_all=True)
+    assert torch.equal(xs[0], ref[0])
+    for i in range(1, 5):
+        assert rel_l2(xs[i], ref[i]) < 1e-3, (i, rel_l2(xs[i], ref[i]))
+
+
+def test_hip_graph_equals_eager(dev):
+    """Graph-replayed steps produce the same states as eager launches (DDPM: noise is an input)."""
+    from lidargen.models.diffusion import ContinuousTimeGaussianDiffusion
+
+    m = _uncond(16, (8, 64), dev)
+    ddpm = ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval().to(dev)
+    outs = []
+    for flag in (True, False):
+        ddpm.use_hip_graph = flag
+        rng = [torch.Generator().manual_seed(i) for i in range(2)]
+        outs.append(ddpm.sample(2, 6, progress=False, rng=rng, return_all=True, mode="ddpm").cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------- roi pooling
+@pytest.mark.parametrize("method", ["max", "avg"])
+def test_roiaware_pool3d(dev, method):
+    """Forward bit-exact vs the numpy restatement of the reference kernels (incl. a voxel that
+    overflows max_pts_each_voxel), backward within fp32 atomics tolerance."""
+    from lidarcrafter_amd.testing import synth_boxes
+    from lidargen.ops.roiaware_pool3d.roiaware_pool3d_utils import RoIAwarePool3d
+    from oracle import roipool as O
+
+    g = np.random.default_rng(3)
+    pts = synth_points(3000, 12)[:, :3].copy()
+    bx = synth_boxes(5, pts, 13)
+    bx[:, 3:6] *= 1.5
+    pts[:200] = bx[0, :3] + g.normal(0, 0.01, (200, 3)).astype(np.float32)  # overflow one voxel
+    feat = g.normal(size=(3000, 4)).astype(np.float32)
+    out_size, cap = (3, 2, 2), 16
+    pooled_r, vox_r, am_r = O.forward(bx, pts, feat, out_size, cap, 0 if method == "max" else 1)
+    assert vox_r[..., 0].max() == cap - 1
+    pool = RoIAwarePool3d(out_size, cap)
+    ft = T(feat).to(dev).requires_grad_(True)
+    y = pool(T(bx).to(dev), T(pts).to(dev), ft, pool_method=method)
+    assert np.array_equal(y.detach().cpu().numpy(), pooled_r)
+    go = g.normal(size=pooled_r.shape).astype(np.float32)
+    y.backward(T(go).to(dev))
+    gin_r = O.backward(vox_r, am_r, go, 3000, 0 if method == "max" else 1)
+    assert np.allclose(ft.grad.cpu().numpy(), gin_r, rtol=1e-5, atol=1e-6)
