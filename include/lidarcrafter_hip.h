@@ -191,6 +191,24 @@ int lc_points_in_boxes_index(const float* boxes, const float* pts, int B, int n_
                              float margin, int32_t* out_idx, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
+ * Range-image pre/post-processing fused into single passes.
+ * lc_range_postprocess: sample [B,2,H,W] in [-1,1] (depth, reflectance) -> out [B,5,H,W] =
+ *   (metric depth, x, y, z, reflectance): LiDARUtility.denormalize / revert_depth / to_xyz
+ *   (lidargen/utils/lidar.py:61-82,109-128) as chained in tools/evaluation/
+ *   sample_and_save_cond.py:119-124.  ray_angles [1,2,H,W] (elevation, azimuth) radians.
+ * lc_condition_preprocess: condition_mask [B,2,H,W] (class id, metric depth) -> out
+ *   [B,num_classes+1,H,W] = one_hot(class) ++ LiDARUtility.convert_depth(depth)
+ *   (sample_and_save_cond.py:106-117, utils/lidar.py:84-107).
+ * depth_format: 0 log_depth, 1 inverse_depth, 2 depth.
+ * ------------------------------------------------------------------------------------------- */
+int lc_range_postprocess(const float* sample, int64_t sample_bs, const float* ray_angles,
+                         float* out, int B, int H, int W, int depth_format, float min_depth,
+                         float max_depth, lc_stream_t s);
+int lc_condition_preprocess(const float* condition_mask, int64_t cm_bs, float* out, int64_t out_bs,
+                            int B, int H, int W, int num_classes, int depth_format,
+                            float min_depth, float max_depth, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
  * RoI-aware voxel pooling of point features: lidargen/ops/roiaware_pool3d/
  *   roiaware_pool3d_utils.py:55-107 (RoIAwarePool3dFunction) -> src/roiaware_pool3d.cpp:30-117
  *   (pybind forward / backward :173-174) -> src/roiaware_pool3d_kernel.cu:39-310.

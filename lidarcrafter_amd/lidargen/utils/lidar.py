@@ -84,6 +84,26 @@ class LiDARUtility(nn.Module):
         return metric * self.get_mask(metric)
 
 
+    # ---- fused single-pass forms of the chains the sampling scripts run (additions) ------------
+    @torch.no_grad()
+    def postprocess(self, sample):
+        """denormalize -> revert_depth -> to_xyz -> cat[depth, xyz, reflectance] ([B,5,H,W]);
+        tools/evaluation/sample_and_save_cond.py:119-124 as ONE kernel."""
+        from lidarcrafter_amd import ops as K
+
+        return K.range_postprocess(sample.float(), self.ray_angles, self.depth_format,
+                                   self.min_depth, self.max_depth)
+
+    @torch.no_grad()
+    def preprocess_condition_mask(self, condition_mask, num_classes: int):
+        """one_hot(class) ++ convert_depth(depth) ([B,num_classes+1,H,W]);
+        sample_and_save_cond.py:106-117 as ONE kernel."""
+        from lidarcrafter_amd import ops as K
+
+        return K.condition_preprocess(condition_mask.float(), num_classes, self.depth_format,
+                                      self.min_depth, self.max_depth)
+
+
 @torch.no_grad()
 def save_points(tensor, fp):
     np.savetxt(fp, tensor.detach().cpu().numpy())

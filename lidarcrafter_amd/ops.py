@@ -465,3 +465,37 @@ def roiaware_pool3d_backward(vox, argmax, grad_out, num_pts: int, method: int) -
                                        grad_in.data_ptr(), N, C, ox, oy, oz, vox.shape[-1], method,
                                        _stream()), "lc_roiaware_pool3d_bwd")
     return grad_in
+
+
+_DEPTH_FMT = {"log_depth": 0, "inverse_depth": 1, "depth": 2}
+
+
+def range_postprocess(sample: torch.Tensor, ray_angles: torch.Tensor, depth_format: str,
+                      min_depth: float, max_depth: float) -> torch.Tensor:
+    """[B,2,H,W] normalised (depth, reflectance) -> [B,5,H,W] (metric depth, x, y, z, reflectance)."""
+    sb = _bs4(sample, "sample")
+    _req(ray_angles, "ray_angles")
+    B, C, H, W = sample.shape
+    if C != 2 or tuple(ray_angles.shape) != (1, 2, H, W) or not ray_angles.is_contiguous():
+        raise ValueError("range_postprocess: sample [B,2,H,W], ray_angles contiguous [1,2,H,W]")
+    out = torch.empty((B, 5, H, W), device=sample.device, dtype=_F32)
+    check(lib().lc_range_postprocess(sample.data_ptr(), sb, ray_angles.data_ptr(), out.data_ptr(),
+                                     B, H, W, _DEPTH_FMT[depth_format], float(min_depth),
+                                     float(max_depth), _stream()), "lc_range_postprocess")
+    return out
+
+
+def condition_preprocess(condition_mask: torch.Tensor, num_classes: int, depth_format: str,
+                         min_depth: float, max_depth: float, out=None) -> torch.Tensor:
+    """[B,2,H,W] (class id, metric depth) -> [B,num_classes+1,H,W] one-hot ++ normalised depth."""
+    cb = _bs4(condition_mask, "condition_mask")
+    B, C, H, W = condition_mask.shape
+    if C != 2:
+        raise ValueError("condition_preprocess: condition_mask must be [B,2,H,W]")
+    if out is None:
+        out = torch.empty((B, num_classes + 1, H, W), device=condition_mask.device, dtype=_F32)
+    ob = _bs4(out, "out")
+    check(lib().lc_condition_preprocess(condition_mask.data_ptr(), cb, out.data_ptr(), ob, B, H, W,
+                                        num_classes, _DEPTH_FMT[depth_format], float(min_depth),
+                                        float(max_depth), _stream()), "lc_condition_preprocess")
+    return out
