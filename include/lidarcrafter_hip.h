@@ -209,6 +209,20 @@ int lc_condition_preprocess(const float* condition_mask, int64_t cm_bs, float* o
                             float min_depth, float max_depth, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
+ * Layout condition rasteriser (the step immediately before the path):
+ * lidargen/dataset/transforms_3d/common.py:99-215 (convert_boxes_to_2d + convert_points_to_2d).
+ * boxes [B,T,box_stride>=8] = (x,y,z,l,w,h,yaw,class,...), n_valid int32 [B] (first n rows used),
+ * -> corners_2d [B,T,4] (x1,y1,x2,y2 normalised; zeros for padding rows; may be NULL),
+ *    condition_mask [B,2,H,W] (class id, centre depth; later boxes overwrite earlier ones),
+ *    loss_weight_map [B,H,W] (may be NULL).  scratch: lc_layout_scratch_bytes(B,T) bytes.
+ * ------------------------------------------------------------------------------------------- */
+int64_t lc_layout_scratch_bytes(int B, int T);
+int lc_layout_condition(const float* boxes, int box_stride, const int32_t* n_valid, int B, int T,
+                        int H, int W, float fov_up_deg, float fov_down_deg, void* scratch,
+                        float* corners_2d, float* condition_mask, float* loss_weight_map,
+                        lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
  * RoI-aware voxel pooling of point features: lidargen/ops/roiaware_pool3d/
  *   roiaware_pool3d_utils.py:55-107 (RoIAwarePool3dFunction) -> src/roiaware_pool3d.cpp:30-117
  *   (pybind forward / backward :173-174) -> src/roiaware_pool3d_kernel.cu:39-310.

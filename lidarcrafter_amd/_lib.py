@@ -46,6 +46,8 @@ SIGNATURES = {
     "lc_project_points": (i32, [vp, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
     "lc_range_postprocess": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "lc_condition_preprocess": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, f32, vp]),
+    "lc_layout_scratch_bytes": (i64, [i32, i32]),
+    "lc_layout_condition": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "lc_roiaware_pool3d_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp,
                                      vp, vp]),
     "lc_roiaware_pool3d_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

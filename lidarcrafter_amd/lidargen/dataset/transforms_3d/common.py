@@ -39,3 +39,22 @@ def load_points_as_images(point_path: str = None, points=None, scan_unfolding: b
     p = p[:, :4].float().contiguous().cuda()
     img, _ = K.project_points(p, H, W, fov_up, fov_down, min_depth, max_depth)
     return img.cpu().numpy() if is_numpy else img
+
+
+def convert_boxes_to_2d(boxes_3d, H: int = 64, W: int = 2048, min_depth: float = 1.45,
+                        max_depth: float = 80.0, fov_up: float = 10.0, fov_down: float = -30.0):
+    """boxes_3d [n, >=8] (x,y,z,l,w,h,yaw,class) -> (corners_2d [n,4], condition_mask [2,H,W],
+    scene_loss_weight_map [H,W]) -- reference :99-181, on the device (lc_layout_condition): the
+    Python loop over boxes becomes one rectangle kernel + one paint kernel.
+    numpy in -> numpy out; CUDA tensor in -> CUDA tensors out."""
+    is_numpy = isinstance(boxes_3d, np.ndarray)
+    if not torch.cuda.is_available():
+        raise RuntimeError("convert_boxes_to_2d needs the MI355X: no CPU fallback on the hot path")
+    b = torch.from_numpy(np.ascontiguousarray(boxes_3d, np.float32)) if is_numpy else boxes_3d
+    b = b.float().contiguous().cuda()[None]
+    n = torch.tensor([b.shape[1]], dtype=torch.int32, device=b.device)
+    c2d, mask, wmap = K.layout_condition(b, n, H, W, fov_up, fov_down, with_weight_map=True)
+    c2d, mask, wmap = c2d[0], mask[0], wmap[0]
+    if is_numpy:
+        return c2d.cpu().numpy(), mask.cpu().numpy(), wmap.cpu().numpy()
+    return c2d, mask, wmap

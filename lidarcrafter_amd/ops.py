@@ -499,3 +499,25 @@ def condition_preprocess(condition_mask: torch.Tensor, num_classes: int, depth_f
                                         num_classes, _DEPTH_FMT[depth_format], float(min_depth),
                                         float(max_depth), _stream()), "lc_condition_preprocess")
     return out
+
+
+def layout_condition(boxes: torch.Tensor, n_valid: torch.Tensor, H: int, W: int, fov_up: float,
+                     fov_down: float, with_weight_map: bool = False):
+    """boxes [B,T,>=8] (x,y,z,l,w,h,yaw,class), n_valid int32 [B] -> (corners_2d [B,T,4],
+    condition_mask [B,2,H,W][, loss_weight_map [B,H,W]])."""
+    _req(boxes, "boxes")
+    if boxes.dim() != 3 or boxes.shape[2] < 8 or not boxes.is_contiguous():
+        raise ValueError("layout_condition: boxes must be contiguous [B,T,>=8]")
+    if n_valid.dtype != torch.int32 or not n_valid.is_cuda:
+        raise TypeError("layout_condition: n_valid must be a CUDA int32 tensor")
+    B, T, S = boxes.shape
+    dev = boxes.device
+    scratch = torch.empty(lib().lc_layout_scratch_bytes(B, T), device=dev, dtype=torch.uint8)
+    c2d = torch.empty((B, T, 4), device=dev, dtype=_F32)
+    mask = torch.empty((B, 2, H, W), device=dev, dtype=_F32)
+    wmap = torch.empty((B, H, W), device=dev, dtype=_F32) if with_weight_map else None
+    check(lib().lc_layout_condition(boxes.data_ptr(), S, n_valid.data_ptr(), B, T, H, W,
+                                    float(fov_up), float(fov_down), scratch.data_ptr(),
+                                    c2d.data_ptr(), mask.data_ptr(), _p(wmap), _stream()),
+          "lc_layout_condition")
+    return (c2d, mask, wmap) if with_weight_map else (c2d, mask)

@@ -114,3 +114,18 @@ def synth_boxes(n: int, pts, seed: int):
                   1).astype(np.float32)
     bx[:, :3] = pts[g.integers(0, len(pts), n), :3]
     return bx
+
+
+def synth_scene_boxes(n: int, seed: int):
+    """n scene boxes float32 [n, 8] = (x, y, z, l, w, h, yaw, class 1..8) at 5-60 m range, one of
+    them straddling the +-pi azimuth seam (exercises the wrap-around case of convert_boxes_to_2d)."""
+    import numpy as np
+
+    g = np.random.default_rng(seed)
+    r = g.uniform(5, 60, n)
+    az = g.uniform(-np.pi, np.pi, n)
+    az[0] = np.pi - 0.01
+    b = np.stack([r * np.cos(az), r * np.sin(az), g.uniform(-2.0, 0.5, n), g.uniform(1.5, 9, n),
+                  g.uniform(1.2, 3, n), g.uniform(1.2, 3.5, n), g.uniform(-np.pi, np.pi, n),
+                  g.integers(1, 9, n).astype(np.float64)], 1)
+    return b.astype(np.float32)

@@ -297,6 +297,21 @@ def sec_boxes():
          count=int(out.sum()))
 
 
+def sec_layout_cond():
+    """convert_boxes_to_2d (dataset/transforms_3d/common.py:99-181) on seeded float32 boxes."""
+    cm = R.ref("dataset.transforms_3d.common")
+    from lidarcrafter_amd.testing import synth_scene_boxes
+    out = {}
+    for tag, n, H, W, seed in (("a", 9, 32, 1024, 0), ("b", 13, 32, 1024, 1), ("c", 5, 64, 2048, 2)):
+        boxes = synth_scene_boxes(n, seed)
+        c2d, mask, wmap = cm.convert_boxes_to_2d(boxes.copy(), H=H, W=W, min_depth=1.45,
+                                                 max_depth=80.0, fov_up=10.0, fov_down=-30.0)
+        out[f"{tag}_corners2d"] = c2d.astype(np.float64)
+        out[f"{tag}_class"] = mask[0].astype(np.uint8)
+        out[f"{tag}_depth"] = mask[1]
+    save("layout_cond", **out)
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":

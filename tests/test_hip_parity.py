@@ -599,3 +599,32 @@ def test_cli_generate(dev, tmp_path):
               "--mode", "ddpm", "--out", str(tmp_path)])
     out = torch.load(tmp_path / "samples.pt")
     assert out.shape == (1, 5, 32, 1024) and torch.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------------- layout raster
+@pytest.mark.parametrize("tag,n,H,W,seed", [("a", 9, 32, 1024, 0), ("b", 13, 32, 1024, 1),
+                                            ("c", 5, 64, 2048, 2)])
+def test_layout_condition_device(dev, golden, tag, n, H, W, seed):
+    """3-D boxes -> class/depth condition mask on the device, bit-exact vs the reference's own
+    output (fixture) and the numpy restatement, incl. the +-pi wrap-around box; batched call with
+    padded rows; chained into the fused preprocess kernel."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_scene_boxes
+    from lidargen.dataset.transforms_3d.common import convert_boxes_to_2d
+    from oracle import layout as OL
+
+    g = golden("layout_cond")
+    boxes = synth_scene_boxes(n, seed)
+    c2d, mask, wmap = convert_boxes_to_2d(boxes, H=H, W=W)
+    assert np.array_equal(mask[0].astype(np.uint8), g[f"{tag}_class"])
+    assert np.array_equal(mask[1], g[f"{tag}_depth"])
+    assert np.allclose(c2d, g[f"{tag}_corners2d"], atol=1e-7)
+    _, _, wref = OL.convert_boxes_to_2d(boxes, H, W)
+    assert np.allclose(wmap, wref, rtol=1e-5)
+    pad = np.zeros((2, 13, 8), np.float32)
+    pad[0, :n], pad[1, :4] = boxes, boxes[:4]
+    nv = torch.tensor([n, 4], dtype=torch.int32, device=dev)
+    c2, m2 = K.layout_condition(T(pad).to(dev), nv, H, W, 10.0, -30.0)
+    assert np.array_equal(m2[0].cpu().numpy(), mask)
+    assert np.array_equal(m2[1].cpu().numpy(), OL.convert_boxes_to_2d(boxes[:4], H, W)[1])
+    assert float(c2[0, n:].abs().max()) == 0.0 if n < 13 else True
