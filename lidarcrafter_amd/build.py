@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+               os.path.join(CSRC, src), "-o", obj] + os.environ.get("LC_EXTRA_HIPCC_FLAGS", "").split()
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for cmd, p in procs:

@@ -21,6 +21,9 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef LC_ABLATE
+#define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
+#endif
 constexpr float X_PRESCALE = 16.0f, W_PRESCALE = 256.0f, OUT_UNSCALE = 1.0f / 4096.0f;
 
 struct ConvArgsH {
@@ -397,6 +400,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         return t > 0 ? t : 0;
     };
     auto store_x = [&](half8* buf, float (&xr)[NXU][8], int i, int ch) {
+        if (LC_ABLATE & 1) { asm volatile("" ::"v"(xr[i][0]), "v"(xr[i][7])); return; }
         const int e = tid + i * NT;
         const int d = e < XU ? e : XU;                  // dummy slot for the padding units
         if (use_gn) {   // fused GroupNorm(+AdaGN)+SiLU of the input; padding units stay exactly 0
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         split_store(xr[i], buf + d, buf + XUP + d);
     };
     auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
+        if (LC_ABLATE & 1) { asm volatile("" ::"v"(wr[2 * i]), "v"(wr[2 * i + 1])); return; }
         const int e = tid + i * NT;
         const int d = e < WU ? e : WU;
         buf[2 * XUP + d] = wr[2 * i];
@@ -441,8 +446,8 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         fetch(0, 0);
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
-            const int s = tap & 1;
-            if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
+            const int s = (LC_ABLATE & 4) ? 0 : (tap & 1);
+            if (tap + 1 < NTAP && !(LC_ABLATE & 4)) fetch(tap + 1, s ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             // loads of this chunk's successor were issued before tap 0; consume them as late as
             // possible: x units over taps [T0, T0+NXU), weight units over the last taps.
@@ -491,8 +496,10 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     for (int ch = 0; ch < nchunk; ++ch) {
         // issue the loads of chunk ch+1 (clamped: unconditional), run the MFMAs of chunk ch and
         // store the loaded chunk into the other buffer during the last taps; one barrier.
-        load_x(xr, min(ch + 1, last));
-        load_w(wr, min(ch + 1, last));
+        if (!(LC_ABLATE & 2)) {
+            load_x(xr, min(ch + 1, last));
+            load_w(wr, min(ch + 1, last));
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc would
                                              // otherwise sink every load next to its use)
         compute(cur, nxt, xr, wr, min(ch + 1, last));
