@@ -493,7 +493,37 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
     for (int i = 0; i < NWU; ++i) store_w(cur, wr, i);
     __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
+    // epilogue operands are fetched early so that the end of the block is stores only: bias before
+    // the K loop, the residual tile while the last chunk's MFMAs run.
+    const int co_wave = co0 + wco * C::TCO_ * 32 + 4 * kh;
+    float bias_r[C::TCO_][16];
+#pragma unroll
+    for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+            bias_r[i][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
+        }
+    float res_r[C::TCO_][C::TPX_][16];
+    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    auto prefetch_res = [&]() {
+#pragma unroll
+        for (int j = 0; j < C::TPX_; ++j) {
+            const int t = wpx * C::TPX_ + j;
+            const int tr = t / C::TPR, tc = t - tr * C::TPR;
+            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+            const bool pok = gh < H && gw < W;
+            const long long poff = (long long)gh * W + gw;
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                    res_r[i][j][r] = (rb && pok && co < a.Co) ? rb[(long long)co * HW + poff] : 0.0f;
+                }
+        }
+    };
+    auto k_iter = [&](int ch) {
         // issue the loads of chunk ch+1 (clamped: unconditional), run the MFMAs of chunk ch and
         // store the loaded chunk into the other buffer during the last taps; one barrier.
         if (!(LC_ABLATE & 2)) {
@@ -505,10 +535,12 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         compute(cur, nxt, xr, wr, min(ch + 1, last));
         __syncthreads();
         half8* t = cur; cur = nxt; nxt = t;
-    }
+    };
+    for (int ch = 0; ch < last; ++ch) k_iter(ch);
+    prefetch_res();          // the last chunk is peeled: no branch inside the steady-state loop
+    k_iter(last);
 
     float* yb = a.y + (long long)b * a.y_bs;
-    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
 #pragma unroll
     for (int j = 0; j < C::TPX_; ++j) {
         const int t = wpx * C::TPX_ + j;
@@ -520,11 +552,9 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         for (int i = 0; i < C::TCO_; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wco * C::TCO_ + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (pok && co < a.Co) {
-                    float v = acc[i][j][r] * OUT_UNSCALE;
-                    if (a.bias) v += a.bias[co];
-                    if (rb) v += rb[(long long)co * HW + poff];
+                    const float v = (acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r];
                     yb[(long long)co * HW + poff] = v * a.out_scale;
                 }
             }
@@ -582,7 +612,7 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
         if (Ci >= 256) return (t128 && blocks(64, 128) >= 256) ? 15 : 13;
         return (t128 && blocks(64, 128) >= 512) ? 5 : 3;
     }
-    if (Ci >= 128) {   // 8-wave pipelined blocks: 270-333 TF when >= 1 block per CU exists
+    if (Ci >= 64) {    // 8-wave pipelined blocks: 230-333 TF when >= 1 block per CU exists
         if (t256 && blocks(64, 256) >= 256) return 23;
         if (t128 && blocks(64, 128) >= 256) return 25;
         return 13;
