@@ -206,8 +206,18 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         graphable = (self.use_hip_graph and x.is_cuda and K.PROFILE is None and st["n"] > 2)
         if graphable and i >= 1:
             if st.get("graph") is None:
-                st["graph"] = self._capture(st)          # step 0 ran eagerly: caches are warm
+                try:
+                    st["graph"] = self._capture(st)      # step 0 ran eagerly: caches are warm
+                except Exception as e:                    # capture is an optimisation only:
+                    import warnings                       # keep launching the same kernels eagerly
+
+                    warnings.warn(f"HIP graph capture failed ({e!r}); continuing with eager launches")
+                    st["graph"] = False
             g = st["graph"]
+            if g is False:
+                self._step_body(st, st["lam"][i], tf, st["coef"][i], noise)
+                st["i"] = i + 1
+                return x
             g["lam"].copy_(st["lam"][i])
             g["coef"].copy_(st["coef"][i])
             if tf is not None:
