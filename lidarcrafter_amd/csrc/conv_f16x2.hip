@@ -41,6 +41,7 @@ struct ConvArgsH {
     // Cgn channels per sample (>= Ci rounded up to 16, zero rows beyond Ci); NULL = plain input
     const f32x4* gn;
     int Cgn, gn_silu;
+    int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles along W of one row band
 };
 
 constexpr int GN_MAX_C = 1024;   // LDS table of fused GroupNorm rows: 16 KB
@@ -308,11 +309,18 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave / C::WPX_, wpx = wave % C::WPX_;
 
+    // persistent over `tpb` consecutive tiles along W (same sample, same row band): the next
+    // tile's first chunk is prefetched under the last chunk of the current tile and the epilogue
+    // stores drain under the next tile's MFMAs, so the per-block prologue / epilogue cost
+    // (~10 us of the 85 us of a 64->64 @32x1024 launch) is paid once per `tpb` tiles.
+    const int tpb = a.tpb;
+    const int groups_w = a.tiles_w / tpb;
     int bx = blockIdx.x;
-    const int tw_i = bx % a.tiles_w; bx /= a.tiles_w;
+    const int tw_g = bx % groups_w; bx /= groups_w;
     const int th_i = bx % a.tiles_h; bx /= a.tiles_h;
     const int b = bx;
-    const int h0 = th_i * C::TH_, w0 = tw_i * C::TW_;
+    const int h0 = th_i * C::TH_;
+    int w0 = tw_g * tpb * C::TW_;                     // first tile of the block
     const int co0 = blockIdx.y * BN;
     const int H = a.H, W = a.W;
     const int HW = H * W;
@@ -320,7 +328,9 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const unsigned nbytes = (unsigned)a.Ci * (unsigned)HW * 4u;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, nbytes, 0x00020000);
 
-    unsigned x_voff[NXU];  // byte offset of (channel-block cb, pixel) inside the sample; OOB = pad
+    unsigned x_row[NXU];   // byte offset of (channel-block cb, row) in the sample, OOB marker = pad
+    int x_col[NXU];        // column of the unit inside the staged row
+    unsigned x_voff[NXU];  // x_row + 4 * (wrapped image column) for the CURRENT tile
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
         const int e = tid + i * NT;
@@ -328,11 +338,19 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         const int rem = e - cb * (XR * XW);
         const int r = rem / XW, c = rem - r * XW;
         const int gh = h0 - HALO + r;
-        int gw = w0 - HALO + c;
-        gw %= W; if (gw < 0) gw += W;
         const bool ok = (e < XU) && gh >= 0 && gh < H;
-        x_voff[i] = ok ? (unsigned)(cb * 8 * HW + gh * W + gw) * 4u : 0xFFFFFFF0u;
+        x_row[i] = ok ? (unsigned)(cb * 8 * HW + gh * W) * 4u : 0xFFFFFFF0u;
+        x_col[i] = c;
     }
+    auto set_voff = [&](int w0t) {
+#pragma unroll
+        for (int i = 0; i < NXU; ++i) {
+            int gw = w0t - HALO + x_col[i];
+            gw %= W; if (gw < 0) gw += W;
+            x_voff[i] = x_row[i] == 0xFFFFFFF0u ? 0xFFFFFFF0u : x_row[i] + 4u * (unsigned)gw;
+        }
+    };
+    set_voff(w0);
     long long w_idx[NWU];  // unit index of this thread's weight units for chunk 0
 #pragma unroll
     for (int i = 0; i < NWU; ++i) {
@@ -353,7 +371,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
         const int e = tid + i * NT;
-        x_cb8[i] = x_voff[i] == 0xFFFFFFF0u ? -1 : 8 * (e / (XR * XW));
+        x_cb8[i] = x_row[i] == 0xFFFFFFF0u ? -1 : 8 * (e / (XR * XW));
     }
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
@@ -523,42 +541,48 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
                 }
         }
     };
-    auto k_iter = [&](int ch) {
-        // issue the loads of chunk ch+1 (clamped: unconditional), run the MFMAs of chunk ch and
-        // store the loaded chunk into the other buffer during the last taps; one barrier.
+    auto k_iter = [&](int ch, int nxt_ch) {
+        // issue the loads of the next chunk (unconditional), run the MFMAs of chunk ch and store
+        // the loaded chunk into the other buffer during the last taps; one barrier.
         if (!(LC_ABLATE & 2)) {
-            load_x(xr, min(ch + 1, last));
-            load_w(wr, min(ch + 1, last));
+            load_x(xr, nxt_ch);
+            load_w(wr, nxt_ch);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc would
                                              // otherwise sink every load next to its use)
-        compute(cur, nxt, xr, wr, min(ch + 1, last));
+        compute(cur, nxt, xr, wr, nxt_ch);
         __syncthreads();
         half8* t = cur; cur = nxt; nxt = t;
     };
-    for (int ch = 0; ch < last; ++ch) k_iter(ch);
-    prefetch_res();          // the last chunk is peeled: no branch inside the steady-state loop
-    k_iter(last);
-
     float* yb = a.y + (long long)b * a.y_bs;
+    for (int tile = 0; tile < tpb; ++tile) {
+        for (int ch = 0; ch < last; ++ch) k_iter(ch, ch + 1);
+        prefetch_res();          // the last chunk is peeled: no branch in the steady-state loop
+        const bool more = tile + 1 < tpb;
+        if (more) set_voff(w0 + C::TW_);              // x offsets of the NEXT tile (uniform branch)
+        k_iter(last, more ? 0 : last);                // prefetches chunk 0 of the next tile
+        // ---- epilogue of this tile: stores only (bias / residual already in registers) --------
 #pragma unroll
-    for (int j = 0; j < C::TPX_; ++j) {
-        const int t = wpx * C::TPX_ + j;
-        const int tr = t / C::TPR, tc = t - tr * C::TPR;
-        const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-        const bool pok = gh < H && gw < W;
-        const long long poff = (long long)gh * W + gw;
+        for (int j = 0; j < C::TPX_; ++j) {
+            const int t = wpx * C::TPX_ + j;
+            const int tr = t / C::TPR, tc = t - tr * C::TPR;
+            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+            const bool pok = gh < H && gw < W;
+            const long long poff = (long long)gh * W + gw;
 #pragma unroll
-        for (int i = 0; i < C::TCO_; ++i) {
+            for (int i = 0; i < C::TCO_; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (pok && co < a.Co) {
-                    const float v = (acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r];
-                    yb[(long long)co * HW + poff] = v * a.out_scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (pok && co < a.Co) {
+                        const float v = (acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r];
+                        yb[(long long)co * HW + poff] = v * a.out_scale;
+                    }
+                    acc[i][j][r] = 0.0f;
                 }
             }
         }
+        w0 += C::TW_;
     }
 }
 
@@ -566,7 +590,16 @@ template <class C>
 int launch_pipe(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
-    dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
+    const int ncot = (a.Co + C::BN - 1) / C::BN;
+    int tpb = 1;   // up to 4 consecutive W tiles per block while every CU still gets a block
+    while (tpb < 4 && a.tiles_w % (tpb * 2) == 0 &&
+           (long long)a.B * a.tiles_h * (a.tiles_w / (tpb * 2)) * ncot >= 256)
+        tpb *= 2;
+    if (C::NTAP == 1) tpb = 1;   // 1x1: a chunk is 6 MFMAs per wave, block-level parallelism wins
+    if (a.tpb > 0) tpb = a.tpb;                          // explicit override (tests)
+    if (a.tiles_w % tpb) tpb = 1;
+    a.tpb = tpb;
+    dim3 grid(a.B * a.tiles_h * (a.tiles_w / tpb), ncot);
     hipLaunchKernelGGL(conv_f16x2_pipe_kernel<C>, grid, dim3(C::NT), 0, st, a);
     return lc_launch_status();
 }
@@ -608,10 +641,8 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     const long long px = (long long)B * H * W;
     auto blocks = [&](int bn, int pxb) { return ((Co + bn - 1) / bn) * ((px + pxb - 1) / pxb); };
     const bool t256 = H % 4 == 0 && W % 64 == 0, t128 = H % 2 == 0 && W % 64 == 0;
-    if (ks == 1) {
-        if (Ci >= 256) return (t128 && blocks(64, 128) >= 256) ? 15 : 13;
+    if (ks == 1)    // one tap per chunk: nothing to pipeline, two resident blocks per CU win (1.3-2x)
         return (t128 && blocks(64, 128) >= 512) ? 5 : 3;
-    }
     if (Ci >= 64) {    // 8-wave pipelined blocks: 230-333 TF when >= 1 block per CU exists
         if (t256 && blocks(64, 256) >= 256) return 23;
         if (t128 && blocks(64, 128) >= 256) return 25;
@@ -679,6 +710,8 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.tiles_h = a.tiles_w = 0;
     a.gn = reinterpret_cast<const f32x4*>(gn_coeffs);
     a.Cgn = gn_cpad; a.gn_silu = gn_silu;
+    a.tpb = 0;
+    if (tile_cfg >= 100) { a.tpb = tile_cfg / 100; tile_cfg %= 100; }   // cfg = tpb*100 + tile id
     if (gn_coeffs && (gn_cpad < (Ci + 15) / 16 * 16 || gn_cpad > GN_MAX_C)) return LC_EINVAL;
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
