@@ -1,0 +1,124 @@
+"""Secondary measurements of SURVEY.md section 8(d) (not the driver's bench line): the C2 shape at
+other batch sizes, the layout-conditioned C3 shape, the 64x2048 shape, projection and
+points-in-boxes bandwidth.  Prints one JSON object; run on the MI355X box via gpurun:
+    python devtools/bench_rows.py [--quick] > gpurun_out/rows.json
+Everything is synthetic (seeded random weights / inputs), inputs resident in HBM before timing."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+GFLOP = {"uncond32": 116.6, "uncond64": 476.5, "cond32": 255.9}   # SURVEY 8(d), per sample-step
+
+
+def timed(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def uncond(dev, B, res, steps, key):
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    cfg = C["nuscenes-unet-uncond"]()
+    if res != (32, 1024):
+        cfg.data.resolution = res
+    ddpm, model, _ = inference.load_model_duffusion_training(cfg)
+    seeded_fill(model, salt=100)
+    ddpm = ddpm.eval().to(dev)
+    g = [torch.Generator().manual_seed(i) for i in range(B)]
+    x_T = torch.stack([torch.randn(*ddpm.sampling_shape, generator=r) for r in g]).to(dev)
+    st = ddpm.begin_sampling(B, steps + 3, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
+    dt = timed(lambda: ddpm.sampling_step(st), steps, warm=3)
+    assert torch.isfinite(st["x"]).all()
+    return {"batch": B, "resolution": list(res), "ms_per_step": round(dt * 1e3, 3),
+            "steps_per_s": round(1 / dt, 2), "sample_steps_per_s": round(B / dt, 1),
+            "algorithmic_tflops": round(B * GFLOP[key] / dt / 1e3, 1)}
+
+
+def cond(dev, B, steps):
+    from lidarcrafter_amd.testing import seeded_fill, synth_layout_batch
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    cfg = C["nuscenes-box-layout-v6"]()
+    ddpm, model, _ = inference.load_model_duffusion_training(cfg)
+    seeded_fill(model, salt=200), seeded_fill(ddpm.condition_model, salt=201)
+    ddpm = ddpm.eval().to(dev)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(B, 32, 1024, seed=53).items()}
+    rng = [torch.Generator().manual_seed(i) for i in range(B)]
+    with torch.inference_mode():
+        x_T = ddpm.randn(B, *ddpm.sampling_shape, rng=rng, device=ddpm.device)
+        t0 = time.perf_counter()
+        cdict = ddpm.get_network_condition(input_dict=batch, only_custom_condition=True)
+        torch.cuda.synchronize()
+        t_enc = time.perf_counter() - t0
+        st = ddpm.begin_sampling(B, steps + 3, None, "ddim", 0.0, x_T=x_T, condition_dict=cdict)
+        dt = timed(lambda: ddpm.sampling_step(st), steps, warm=3)
+        x = st["x"]
+    assert torch.isfinite(x).all()
+    return {"batch": B, "resolution": [32, 1024], "ms_per_step": round(dt * 1e3, 3),
+            "steps_per_s": round(1 / dt, 2), "sample_steps_per_s": round(B / dt, 1),
+            "algorithmic_tflops": round(B * GFLOP["cond32"] / dt / 1e3, 1),
+            "layout_encoder_ms_once_per_batch": round(t_enc * 1e3, 2)}
+
+
+def projection(dev, N):
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_points
+
+    pts = torch.from_numpy(synth_points(N, seed=3)).to(dev)
+    H, W = 32, 1024
+    dt = timed(lambda: K.project_points(pts, H, W, 10.0, -30.0, 1.45, 80.0), 50, warm=5)
+    algo = 16 * N + 8 * N + 24 * H * W
+    return {"points": N, "us": round(dt * 1e6, 1), "algorithmic_bytes": algo,
+            "GBps": round(algo / dt / 1e9, 1), "frac_of_hbm_peak": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "includes the wrapper's three torch.empty allocations; latency-bound at this size"}
+
+
+def pib(dev, N, nbox):
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_boxes, synth_points
+
+    p = synth_points(N, seed=4)
+    pts = torch.from_numpy(p[:, :3].copy()).to(dev)
+    boxes = torch.from_numpy(synth_boxes(nbox, p, seed=5)).to(dev)
+    dt = timed(lambda: K.points_in_boxes_mask(pts, boxes, 1e-2), 50, warm=5)
+    algo = 12 * N + 4 * N * nbox
+    return {"points": N, "boxes": nbox, "us": round(dt * 1e6, 1), "algorithmic_bytes": algo,
+            "GBps": round(algo / dt / 1e9, 1), "frac_of_hbm_peak": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    out = {"device": torch.cuda.get_device_name(0)}
+    out["uncond_32x1024"] = [uncond(dev, B, (32, 1024), 20 if B <= 8 else 8, "uncond32")
+                             for B in ((1, 8) if args.quick else (1, 2, 8, 32))]
+    out["cond_layout_v6_32x1024"] = [cond(dev, B, 10) for B in ((8,) if args.quick else (1, 8))]
+    if not args.quick:
+        out["uncond_64x2048"] = [uncond(dev, 4, (64, 2048), 6, "uncond64")]
+    out["projection"] = [projection(dev, N) for N in (34720, 131072, 1 << 22)]
+    out["points_in_boxes_mask"] = [pib(dev, N, nb) for N, nb in ((34720, 13), (1 << 22, 13))]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

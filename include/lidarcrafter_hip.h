@@ -146,6 +146,17 @@ int lc_attention_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
                      float* o, int64_t o_bs, int64_t o_hs, int64_t o_cs,
                      int B, int heads, int Lq, int Lk0, int Lk1, int dqk, int dpos, int dv,
                      float scale, lc_stream_t s);
+/* Same contract, f16x2-split arithmetic (the default of the Python layer): q, k, p and v are split
+ * into fp16 hi/lo parts of the pre-scaled fp32 values, every product is accumulated in fp32 as
+ * ah*bh + ah*bl + al*bh with v_mfma_f32_32x32x16_f16 (per-product error ~5e-7, same tolerance as
+ * lc_attention_fwd in tests/test_hip_parity.py). */
+int lc_attention_f16x2_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
+                           const lc_cm_operand* k, const lc_cm_operand* k_pos,
+                           const lc_cm_operand* v, const lc_cm_operand* k2,
+                           const lc_cm_operand* k2_pos, const lc_cm_operand* v2, float* o,
+                           int64_t o_bs, int64_t o_hs, int64_t o_cs, int B, int heads, int Lq,
+                           int Lk0, int Lk1, int dqk, int dpos, int dv, float scale,
+                           lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse-diffusion update, one fused elementwise pass:

@@ -317,8 +317,14 @@ def sinusoid(t: torch.Tensor, channels: int, max_period: float = 10_000.0) -> to
 
 
 # ------------------------------------------------------------------------------------ attention
+# "f16x2" (default): hi/lo-split fp16 MFMA with fp32 accumulation (fp32-class accuracy, the same
+# scheme as the conv); "f32": the fp32-MFMA kernel.
+ATTN_PRECISION = _os.environ.get("LC_ATTN_PRECISION", "f16x2")
+
+
 def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None, q_pos=None, k_pos=None,
-                 k2_pos=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 k2_pos=None, out: Optional[torch.Tensor] = None,
+                 precision: Optional[str] = None) -> torch.Tensor:
     """Channel-major attention.  q:[B, heads*dqk, Lq]  k:[B, heads*dqk, Lk0]  v:[B, heads*dv, Lk0]
     (views with arbitrary batch/channel strides, unit token stride).  Optional positional parts
     q_pos/k_pos/k2_pos [B, heads*dpos, L] are concatenated to each head's q/k channels inside the
@@ -349,12 +355,15 @@ def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None, q_pos=None
         return C.byref(CmOperand(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else 0,
                                  d * t.stride(1), t.stride(1)))
 
+    prec = precision or ATTN_PRECISION
+    if prec not in ("f32", "f16x2"):
+        raise ValueError(prec)
+    fn = lib().lc_attention_f16x2_fwd if prec == "f16x2" else lib().lc_attention_fwd
     with _Timed("attention", 2.0 * B * heads * Lq * (Lk0 + Lk1) * (dqk + dpos + dv)):
-        check(lib().lc_attention_fwd(op(q, dqk), op(q_pos, dpos), op(k, dqk), op(k_pos, dpos),
-                                     op(v, dv), op(k2, dqk), op(k2_pos, dpos), op(v2, dv),
-                                     out.data_ptr(), out.stride(0), dv * out.stride(1),
-                                     out.stride(1), B, heads, Lq, Lk0, Lk1, dqk, dpos, dv,
-                                     float(scale), _stream()), "lc_attention_fwd")
+        check(fn(op(q, dqk), op(q_pos, dpos), op(k, dqk), op(k_pos, dpos), op(v, dv), op(k2, dqk),
+                 op(k2_pos, dpos), op(v2, dv), out.data_ptr(), out.stride(0), dv * out.stride(1),
+                 out.stride(1), B, heads, Lq, Lk0, Lk1, dqk, dpos, dv, float(scale), _stream()),
+              "lc_attention_fwd")
     return out
 
 
