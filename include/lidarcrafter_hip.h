@@ -253,6 +253,33 @@ int lc_roiaware_pool3d_bwd(const int32_t* pts_idx_of_voxels, const int32_t* argm
                            int out_x, int out_y, int out_z, int max_pts_each_voxel,
                            int pool_method, lc_stream_t s);
 
+/* ---------------------------------------------------------------------------------------------
+ * Point-set glue of the autoregressive (temporal) loop, SURVEY.md section 8(f)-2 -- keeps
+ * tools/evaluation/sample_and_save_temporal.py:262-331 on the device between frames.
+ * Points are [N,4] float32 rows (x, y, z, intensity), 16-byte aligned.
+ *  lc_transform_points: out.xyz = T[0:3,0:3] p + T[0:3,3] (T row-major 4x4 of doubles on the HOST,
+ *    product in fp64, rounded once), intensity copied: `(Ts @ homo_pts.T).T`
+ *    tools/vis_tools/utils/pipe_related.py:245-249; warp_lidar_future common.py:59-112; the
+ *    object <-> box-frame moves pipe_related.py:56-66,263-268 are the same op with another T.
+ *  lc_image_to_points: xyz [3,H,W] (+reflectance [H,W]) -> rows, times the background mask
+ *    !(cond[h,w] > 0) when cond != NULL; keep[i] = 0 for |xyz| <= min_norm (min_norm < 0: off)
+ *    and for |x|,|y| < ego_radius (<= 0: off): pipe_related.py:68-75,274-283 and :11-13.
+ *  lc_points_in_boxes_mask4: points_in_boxes_cpu on [N,4] rows; out_mask [n_boxes, N] and / or
+ *    out_count [N] = number of boxes containing the point (delete_fg_points :266-272).
+ *  lc_compact_points: out = rows[keep != 0] (or keep == 0 when keep_if_zero) in input order --
+ *    numpy boolean indexing; count[0] = rows kept; src_index (may be NULL) = source row of each
+ *    kept row; scratch = lc_compact_scratch_elems(N) int32.  Three launches, no host sync.
+ * ------------------------------------------------------------------------------------------- */
+int lc_transform_points(const float* pts, int N, const double* T16_host, float* out, lc_stream_t s);
+int lc_image_to_points(const float* xyz, int64_t plane_stride, const float* refl, const float* cond,
+                       int H, int W, float refl_scale, float min_norm, float ego_radius, float* pts,
+                       int32_t* keep, lc_stream_t s);
+int lc_points_in_boxes_mask4(const float* boxes, int n_boxes, const float* pts4, int n_pts,
+                             float margin, int32_t* out_mask, int32_t* out_count, lc_stream_t s);
+int64_t lc_compact_scratch_elems(int N);
+int lc_compact_points(const float* rows, const int32_t* keep, int N, int keep_if_zero, float* out,
+                      int32_t* src_index, int32_t* count, int32_t* scratch, lc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

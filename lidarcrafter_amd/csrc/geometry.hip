@@ -90,6 +90,27 @@ __global__ __launch_bounds__(256) void pib_mask_kernel(const float* __restrict__
     for (int k = 0; k < nb; ++k) out[(long long)k * np + j] = pt_in_box(x, y, z, sb + 7 * k, margin);
 }
 
+// [N,4] points (x, y, z, intensity): mask rows like points_in_boxes_cpu and, per point, the number
+// of boxes containing it (delete_fg_points / get_temporal_boxes_3d, pipe_related.py:52-62,266-272)
+__global__ __launch_bounds__(256) void pib_mask4_kernel(const float* __restrict__ boxes, int nb,
+                                                       const float* __restrict__ pts, int np,
+                                                       float margin, int* __restrict__ out_mask,
+                                                       int* __restrict__ out_count) {
+    extern __shared__ float sb[];
+    for (int i = threadIdx.x; i < nb * 7; i += 256) sb[i] = boxes[i];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= np) return;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pts + 4ll * j);
+    int cnt = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int in = pt_in_box(p.x, p.y, p.z, sb + 7 * k, margin);
+        if (out_mask) out_mask[(long long)k * np + j] = in;
+        cnt += in;
+    }
+    if (out_count) out_count[j] = cnt;
+}
+
 __global__ __launch_bounds__(256) void pib_index_kernel(const float* __restrict__ boxes, int nb,
                                                        const float* __restrict__ pts, int np,
                                                        float margin, int* __restrict__ out) {
@@ -146,5 +167,17 @@ extern "C" int lc_points_in_boxes_index(const float* boxes, const float* pts, in
     hipLaunchKernelGGL(pib_index_kernel, dim3((n_pts + 255) / 256, B), dim3(256),
                        n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
                        out_idx);
+    return lc_launch_status();
+}
+
+extern "C" int lc_points_in_boxes_mask4(const float* boxes, int n_boxes, const float* pts4, int n_pts,
+                                        float margin, int32_t* out_mask, int32_t* out_count,
+                                        lc_stream_t s) {
+    if (!boxes || !pts4 || (!out_mask && !out_count) || n_boxes <= 0 || n_pts <= 0) return LC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(pts4) & 15) return LC_EINVAL;
+    if (n_boxes * 7 * sizeof(float) > 60000) return LC_EUNSUP;
+    hipLaunchKernelGGL(pib_mask4_kernel, dim3((n_pts + 255) / 256), dim3(256),
+                       n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts4, n_pts, margin,
+                       out_mask, out_count);
     return lc_launch_status();
 }

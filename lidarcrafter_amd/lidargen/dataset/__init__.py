@@ -1,7 +1,10 @@
-"""Dataset registry.  The reference's datasets need nuScenes on disk plus loguru / clip /
+"""Dataset registry.  The reference's nuScenes datasets need nuScenes on disk plus loguru / clip /
 pyquaternion (OUT OF SCOPE); the names resolve so `from lidargen.dataset
-import __all__` works, and constructing one says why it is unavailable.  The projection they call
-per frame (transforms_3d.common.load_points_as_images) IS on the path and runs on the GPU."""
+import __all__` works, and constructing one says why it is unavailable.  `CustomDataset`
+(user-supplied boxes / points, the item builder of the temporal loop) and the
+projection every dataset calls per frame (transforms_3d.common.load_points_as_images) ARE on the
+path and run on the GPU."""
+from .custom_dataset import CustomDataset
 
 
 def _stub(name):
@@ -17,5 +20,5 @@ __all__ = {
     "nuscenes": _stub("NuscDataset"),
     "nuscenes-object": _stub("NuscObjectDataset"),
     "nuscenes-temporal": _stub("NuscTemporalDataset"),
-    "custom": _stub("CustomDataset"),
+    "custom": CustomDataset,
 }

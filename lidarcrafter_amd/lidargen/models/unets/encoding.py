@@ -43,7 +43,7 @@ class FourierFeatures(nn.Module):
             f = self.freqs.detach().float().cpu()[:, :, 0, 0]           # [n, 2]
             ang = torch.einsum("nk,bkhw->bnhw", f, c) + self.phase.detach().cpu()[None, :, None, None]
             enc = torch.cat([ang.sin(), ang.cos()], dim=1).contiguous()
-            self._cache = (key, enc.to(coords.device))
+            self._cache = (key, enc.to(coords.device), coords)   # holds coords: see key
         return self._cache[1]
 
     def extra_repr(self):

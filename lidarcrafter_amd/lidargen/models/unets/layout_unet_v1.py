@@ -139,8 +139,11 @@ class ObjectAwareCrossAttention(nn.Module):
             B, E, L2 = cls.shape
             content = K.add_scale(cond["xf_out"].reshape(B, E, 1, L2), cls.view(B, E, 1, L2), 0.5)
             kv = self.layout_content_embedding_projector(content.view(B, E, L2))
-            self._cond_cache = (key, pos_img, pos_lay, kv[:, :C], kv[:, C:])
-        return self._cond_cache[1:]
+            # the keyed tensors are kept alive by the cache: their addresses cannot be handed to
+            # a different condition while it is valid (versions are not tracked in inference mode)
+            hold = (img, cond["obj_bbox_embedding"], cond["xf_out"], cond["obj_class_embedding"])
+            self._cond_cache = (key, pos_img, pos_lay, kv[:, :C], kv[:, C:], hold)
+        return self._cond_cache[1:5]
 
     def forward(self, x, cond_kwargs, out=None):
         B, C, H, W = x.shape
@@ -324,10 +327,13 @@ class LayoutUnetV1(nn.Module):
 
     def prepare_condition(self, layout_outputs: dict):
         """Compute everything that depends only on the layout condition (once per batch)."""
+        if self._in_buf is not None:          # a new condition: recopy its channels next forward
+            self._in_buf = (self._in_buf[0], self._in_buf[1], None)
         seqs = list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
         for s in seqs:
             for m in s:
                 if isinstance(m, ObjectAwareCrossAttention):
+                    m._cond_cache = None      # never trust a cache across conditions
                     m.condition_operands(layout_outputs)
 
     def forward(self, x, cond_dict, time_features=None):
@@ -345,8 +351,9 @@ class LayoutUnetV1(nn.Module):
             K.copy_into(buf[:, :cx], x)
         if "concat_cond" in lay:
             cc = lay["concat_cond"]
-            ck = (cc.data_ptr(), _ver(cc))
-            if self._in_buf[2] != ck:   # condition channels are step-invariant: copy once
+            ck = (cc.data_ptr(), _ver(cc), cc)   # holds cc: its address cannot be reused meanwhile
+            if self._in_buf[2] is None or self._in_buf[2][:2] != ck[:2]:
+                # condition channels are step-invariant: copy once per condition
                 K.copy_into(buf[:, cx:cx + cc.shape[1]], cc.float().contiguous())
                 self._in_buf = (self._in_buf[0], buf, ck)
         dev = x.device

@@ -446,6 +446,97 @@ def points_in_boxes_index(points: torch.Tensor, boxes: torch.Tensor, margin: flo
     return out
 
 
+# ------------------------------------------------------------------------------------ temporal glue
+def _pts4(t: torch.Tensor, name: str) -> int:
+    _req(t, name)
+    if t.dim() != 2 or t.shape[1] != 4 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous [N,4] points, got {tuple(t.shape)}")
+    return t.shape[0]
+
+
+def transform_points(points: torch.Tensor, T, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N,4] rows (x,y,z,intensity) -> (T[:3,:3] p + T[:3,3], intensity); T: 4x4 host matrix
+    (numpy / nested list / CPU tensor), product in fp64 rounded once (pipe_related.py:245-249)."""
+    import ctypes as C
+    import numpy as np
+
+    N = _pts4(points, "points")
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64))
+    if T.shape != (4, 4):
+        raise ValueError("transform_points: T must be 4x4")
+    if out is None:
+        out = torch.empty_like(points)
+    elif _pts4(out, "out") != N:
+        raise ValueError("transform_points: out shape mismatch")
+    check(lib().lc_transform_points(points.data_ptr(), N, T.ctypes.data_as(C.POINTER(C.c_double)),
+                                    out.data_ptr(), _stream()), "lc_transform_points")
+    return out
+
+
+def image_to_points(xyz: torch.Tensor, refl: Optional[torch.Tensor] = None,
+                    cond: Optional[torch.Tensor] = None, refl_scale: float = 1.0,
+                    min_norm: float = -1.0, ego_radius: float = 0.0):
+    """xyz [3,H,W] (+ refl [H,W] / [1,H,W]) -> (rows [H*W,4], keep int32 [H*W]); `cond` [H,W]:
+    pixels with cond > 0 are zeroed (foreground removed).  See lc_image_to_points."""
+    _req(xyz, "xyz")
+    if xyz.dim() != 3 or xyz.shape[0] != 3 or xyz.stride(2) != 1 or xyz.stride(1) != xyz.shape[2]:
+        raise ValueError("image_to_points: xyz must be [3,H,W] with contiguous planes")
+    H, W = xyz.shape[1:]
+
+    def plane(t, name):
+        if t is None:
+            return None
+        _req(t, name)
+        t = t.reshape(H, W)
+        if not t.is_contiguous():
+            raise ValueError(f"image_to_points: {name} must be a contiguous [H,W] plane")
+        return t
+
+    refl, cond = plane(refl, "refl"), plane(cond, "cond")
+    pts = torch.empty((H * W, 4), device=xyz.device, dtype=_F32)
+    keep = torch.empty((H * W,), device=xyz.device, dtype=torch.int32)
+    check(lib().lc_image_to_points(xyz.data_ptr(), xyz.stride(0), _p(refl), _p(cond), H, W,
+                                   float(refl_scale), float(min_norm), float(ego_radius),
+                                   pts.data_ptr(), keep.data_ptr(), _stream()), "lc_image_to_points")
+    return pts, keep
+
+
+def points_in_boxes_mask4(points: torch.Tensor, boxes: torch.Tensor, margin: float = 1e-2,
+                          want_mask: bool = True, want_count: bool = True):
+    """points_in_boxes_cpu semantics on [N,4] rows: (mask int32 [K,N] | None, count int32 [N] | None)."""
+    N = _pts4(points, "points")
+    _req(boxes, "boxes")
+    boxes = boxes.contiguous()
+    K = boxes.shape[0]
+    mask = torch.empty((K, N), device=points.device, dtype=torch.int32) if want_mask else None
+    cnt = torch.empty((N,), device=points.device, dtype=torch.int32) if want_count else None
+    if N > 0 and K > 0:
+        check(lib().lc_points_in_boxes_mask4(boxes.data_ptr(), K, points.data_ptr(), N, float(margin),
+                                             _p(mask), _p(cnt), _stream()), "lc_points_in_boxes_mask4")
+    elif cnt is not None:
+        cnt.zero_()
+    return mask, cnt
+
+
+def compact_points(rows: torch.Tensor, keep: torch.Tensor, keep_if_zero: bool = False,
+                   return_index: bool = False):
+    """rows[keep != 0] (or == 0) in input order, like numpy boolean indexing.  One 4-byte
+    device->host read (the number of kept rows) per call."""
+    N = _pts4(rows, "rows")
+    _req_i32 = keep.is_cuda and keep.dtype == torch.int32 and keep.is_contiguous() and keep.numel() == N
+    if not _req_i32:
+        raise ValueError("compact_points: keep must be a contiguous int32 device tensor of N flags")
+    out = torch.empty_like(rows)
+    idx = torch.empty((max(N, 1),), device=rows.device, dtype=torch.int32) if return_index else None
+    count = torch.empty((1,), device=rows.device, dtype=torch.int32)
+    scratch = torch.empty((lib().lc_compact_scratch_elems(N),), device=rows.device, dtype=torch.int32)
+    check(lib().lc_compact_points(rows.data_ptr(), keep.data_ptr(), N, int(keep_if_zero),
+                                  out.data_ptr(), _p(idx), count.data_ptr(), scratch.data_ptr(),
+                                  _stream()), "lc_compact_points")
+    n = int(count.item())
+    return (out[:n], idx[:n]) if return_index else out[:n]
+
+
 def roiaware_pool3d_forward(rois, pts, pts_feature, out_size, max_pts_each_voxel: int, method: int):
     """-> (pooled [N,X,Y,Z,C], pts_idx_of_voxels int32 [N,X,Y,Z,max_pts], argmax int32 [N,X,Y,Z,C])."""
     for n_, t_ in (("rois", rois), ("pts", pts), ("pts_feature", pts_feature)):

@@ -129,3 +129,20 @@ def synth_scene_boxes(n: int, seed: int):
                   g.uniform(1.2, 3, n), g.uniform(1.2, 3.5, n), g.uniform(-np.pi, np.pi, n),
                   g.integers(1, 9, n).astype(np.float64)], 1)
     return b.astype(np.float32)
+
+
+def synth_temporal_inputs(seed=0, K=5, T=6):
+    """Seeded inputs of the temporal glue: ego + K object per-step offsets, K boxes, a point set."""
+    import numpy as np
+
+    g = np.random.default_rng(seed)
+    ego = np.stack([g.normal(0.05, 0.02, T), g.uniform(0.3, 1.2, T)], 1)      # mostly forward (+y)
+    ego[2] = [0.01, 0.02]                                                      # a < 0.1 m step
+    obj = g.normal(0.0, 0.6, (K, T, 2))
+    obj[1] = 0.0                                                               # a standing object
+    obj[2, 3] = 0.0                                                            # stops for one step
+    trajs = np.concatenate([ego[None], obj], 0)                                # [1+K, T, 2] offsets
+    r, az = g.uniform(6, 40, K), g.uniform(-np.pi, np.pi, K)
+    boxes = np.stack([r * np.cos(az), r * np.sin(az), g.uniform(-1.5, 0.0, K), g.uniform(1.5, 6, K),
+                      g.uniform(1.2, 2.5, K), g.uniform(1.2, 2.5, K), g.uniform(-np.pi, np.pi, K)], 1)
+    return trajs, boxes

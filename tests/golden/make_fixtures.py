@@ -312,6 +312,35 @@ def sec_layout_cond():
     save("layout_cond", **out)
 
 
+def sec_temporal():
+    """tools/vis_tools/utils/common.py (numpy only: imported by file path) warp_lidar_future :59-112,
+    warp_boxes_future :115-172, compute_inter_frame_transforms :174-222, and
+    lidargen/dataset/utils.py rotate_points_along_z :37-59, on seeded inputs."""
+    import importlib.util
+    from lidarcrafter_amd.testing import synth_points, synth_temporal_inputs
+
+    spec = importlib.util.spec_from_file_location(
+        "ref_vis_common", R.REF + "/tools/vis_tools/utils/common.py")
+    vc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vc)
+    du = R.ref("dataset.utils")
+    trajs, boxes = synth_temporal_inputs()
+    a = np.insert(trajs, 0, 0, axis=1)
+    acc = np.cumsum(a, axis=1)
+    a = acc[:, 1:] - acc[:, :-1]
+    ego_xy, obj_xy = np.cumsum(a[0], axis=0), np.cumsum(a[1:], axis=1)
+    P = synth_points(800, seed=7)
+    out = dict(trajs=trajs, boxes=boxes, ego_xy=ego_xy, obj_xy=obj_xy,
+               warp_lidar=vc.warp_lidar_future(P=P, future_xy=ego_xy, z0=0.0),
+               warp_lidar64=vc.warp_lidar_future(P=P.astype(np.float64), future_xy=ego_xy, z0=0.0),
+               warp_boxes=vc.warp_boxes_future(boxes0=boxes, traj_obj=obj_xy, traj_ego=ego_xy, z_e=0.0),
+               Ts=vc.compute_inter_frame_transforms(future_xy=ego_xy, z0=0.0))
+    ang = np.array([0.3, -2.1], np.float64)
+    pts = np.stack([P[:300], P[300:600]])
+    out["rot"] = du.rotate_points_along_z(pts, ang)
+    save("temporal", **out)
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":

@@ -638,3 +638,184 @@ def test_layout_condition_device(dev, golden, tag, n, H, W, seed):
     assert np.array_equal(m2[0].cpu().numpy(), mask)
     assert np.array_equal(m2[1].cpu().numpy(), OL.convert_boxes_to_2d(boxes[:4], H, W)[1])
     assert float(c2[0, n:].abs().max()) == 0.0 if n < 13 else True
+
+
+# ------------------------------------------------------------------------------------- temporal glue
+@pytest.mark.parametrize("N", [0, 1, 255, 1023, 1024, 1025, 34720, 300001])
+def test_compact_points(dev, N):
+    from lidarcrafter_amd import ops as K
+
+    g = np.random.default_rng(N)
+    rows = torch.from_numpy(g.normal(size=(N, 4)).astype(np.float32)).to(dev)
+    flags = torch.from_numpy((g.random(N) < 0.37).astype(np.int32) * g.integers(1, 5, N).astype(np.int32)).to(dev)
+    out, idx = K.compact_points(rows, flags, return_index=True)
+    sel = np.nonzero(flags.cpu().numpy())[0]
+    assert np.array_equal(idx.cpu().numpy(), sel)
+    assert torch.equal(out.cpu(), rows.cpu()[sel])
+    out0 = K.compact_points(rows, flags, keep_if_zero=True)
+    assert torch.equal(out0.cpu(), rows.cpu()[np.nonzero(flags.cpu().numpy() == 0)[0]])
+
+
+def test_transform_points_bit_exact(dev, golden):
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_points
+    from oracle import temporal as OT
+
+    g = golden("temporal")
+    P = synth_points(5000, seed=7)
+    d = torch.from_numpy(P).to(dev)
+    for T in list(g["Ts"]) + [OT.warp_lidar_matrix(g["ego_xy"], 2), OT.box_frame_matrix(g["boxes"][1], False),
+                              OT.box_frame_matrix(g["boxes"][1], True)]:
+        assert np.array_equal(K.transform_points(d, T).cpu().numpy(), OT.apply_T(P, T))
+    # against the reference's own float64 result (warp_lidar_future on float64 points)
+    w = K.transform_points(torch.from_numpy(synth_points(800, seed=7)).to(dev),
+                           OT.warp_lidar_matrix(g["ego_xy"], 3)).cpu().numpy()
+    assert np.abs(w - g["warp_lidar64"][3]).max() < 1e-5
+
+
+def _temporal_scene(seed, H=32, W=1024, n_pts=30000, K_=5):
+    """First-frame dict like sample_and_save_temporal.py:281-289, built with the oracle."""
+    from lidarcrafter_amd.testing import synth_boxes, synth_points, synth_temporal_inputs
+    from oracle import temporal as OT
+
+    trajs, _ = synth_temporal_inputs(seed, K=K_)
+    pts = synth_points(n_pts, seed=seed + 100)
+    pts[:, 3] = np.floor(pts[:, 3])
+    boxes = synth_boxes(K_, pts, seed=seed + 200)
+    boxes[:, 3:6] += 3.0                                   # big enough to own some pixels
+    names = ["ego"] + [OT.CLASS_NAMES[i % 8] for i in range(K_)]
+    gt_boxes = np.concatenate([np.zeros((1, 7), np.float32), boxes]).astype(np.float64)
+    item = OT.custom_item(pts, gt_boxes, names, H, W)
+    first = dict(gt_fut_trajs=trajs, xyz=item["xyz"], reflectance=item["reflectance"],
+                 gt_boxes=gt_boxes, gt_names=names, condition_mask=item["condition_mask"])
+    return first, pts, item
+
+
+def test_custom_dataset_item(dev):
+    """CustomDataset.__getitem__ + pre_process on the device vs the oracle restatement."""
+    import lidargen  # noqa: F401
+    from lidargen.dataset import __all__ as DS
+    from oracle import temporal as OT
+
+    first, pts, ref = _temporal_scene(3)
+    ds = DS["custom"]([dict(points=pts, gt_boxes=first["gt_boxes"].copy(), gt_names=first["gt_names"])])
+    it = ds[0]
+    for k in ("xyz", "reflectance", "depth", "mask", "condition_mask"):
+        assert np.array_equal(it[k].cpu().numpy(), ref[k]), k
+    for k in ("scaled_gt_boxes", "gt_boxes_2d", "fg_encoding_box", "is_valid_obj"):
+        assert np.allclose(np.asarray(it[k]), ref[k], rtol=1e-6, atol=1e-6), k
+    ds.task = "autoregressive_generation"
+    it2 = ds[0]
+    ref2 = OT.custom_item(pts, first["gt_boxes"].copy(), first["gt_names"], task="autoregressive_generation")
+    assert np.array_equal(it2["autoregressive_cond"].cpu().numpy(), ref2["autoregressive_cond"])
+    assert "xyz" not in it2
+    batch = ds.collate_fn([it2, ds[0]])
+    assert batch["autoregressive_cond"].shape == (2, 2, 32, 1024) and batch["batch_size"] == 2
+    assert batch["scaled_gt_boxes"].shape == (2, 13, 9) and batch["is_valid_obj"].shape == (2, 13)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_temporal_frame_glue(dev, seed):
+    """get_temporal_boxes_3d -> get_next_frame_points -> delete_fg_points for two frames, device
+    vs oracle: identical point selections and order, coordinates bit-equal (same float64 4x4s)."""
+    import lidargen  # noqa: F401
+    from lidargen.utils import temporal as T
+    from oracle import temporal as OT
+
+    first, _, _ = _temporal_scene(seed)
+    dfirst = dict(first)
+    for k in ("xyz", "reflectance", "condition_mask"):
+        dfirst[k] = torch.from_numpy(np.ascontiguousarray(first[k])).to(dev)
+    names = first["gt_names"]
+    bg, fut_bg, boxes, fut_boxes, Ts, obj_pts, obj_int = T.get_temporal_boxes_3d(dfirst, M=None)
+    rbg, rfut_bg, rboxes, rfut_boxes, rTs, robj_pts, robj_int = OT.get_temporal_boxes_3d(first, M=None)
+    assert np.array_equal(bg.cpu().numpy(), rbg)
+    assert np.array_equal(fut_bg.cpu().numpy(), rfut_bg)
+    assert np.allclose(fut_boxes, rfut_boxes, rtol=0, atol=1e-12) and np.array_equal(Ts, rTs)
+    assert sum(p.shape[0] for p in obj_pts) > 50            # the scene does have object points
+    for k in range(len(obj_pts)):
+        assert np.array_equal(obj_pts[k].cpu().numpy(), robj_pts[k]), k
+        assert np.array_equal(obj_int[k].cpu().numpy(), robj_int[k]), k
+    cur, rcur = bg, rbg
+    for t in range(2):
+        nxt = T.get_next_frame_points(cur, obj_pts, obj_int, rfut_boxes[:, t], names, rTs[t])
+        rnxt = OT.get_next_frame_points(rcur, robj_pts, robj_int, rfut_boxes[:, t], names, rTs[t])
+        assert np.array_equal(nxt.cpu().numpy(), rnxt), t
+        comb = torch.cat([fut_bg[t], nxt], dim=0).contiguous()
+        rcomb = np.concatenate([rfut_bg[t], rnxt], axis=0)
+        cur = T.delete_fg_points(comb, rfut_boxes[:, t])
+        rcur = OT.delete_fg_points(rcomb, rfut_boxes[:, t])
+        assert np.array_equal(cur.cpu().numpy(), rcur), t
+        assert 0 < cur.shape[0] < comb.shape[0]
+
+
+def test_generate_sequence_device_loop(dev):
+    """sample_and_save_temporal.py:198-331 as one device-resident loop (reduced-width models at
+    8x64): frame 0 layout-conditioned, frames 1-2 autoregressive; deterministic under per-sample
+    generators, finite, and frame t+1's autoregressive condition really is the re-projected,
+    ego-motion-compensated frame t (checked against the oracle glue for sample 0)."""
+    import lidargen  # noqa: F401
+    from lidargen.dataset.custom_dataset import CustomDataset, DataConfig
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from lidargen.utils import temporal as T
+    from lidargen.utils.lidar import LiDARUtility
+    from lidarcrafter_amd.testing import synth_scene_boxes, synth_temporal_inputs
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    H, W, B, K_ = 8, 64, 2, 4
+    m0, e0 = build_cond_pair((H, W), 8, 32, cond_out=10)
+    m1, e1 = build_cond_pair((H, W), 8, 32, cond_out=11)
+    ddpm = CondContinuousTimeGaussianDiffusion(m0, e0, cond_mode="concat").eval().to(dev)
+    auto = CondContinuousTimeGaussianDiffusion(m1, e1, cond_mode="concat").eval().to(dev)
+    lu = LiDARUtility(resolution=(H, W), depth_format="log_depth", min_depth=1.45, max_depth=80.0,
+                      ray_angles=m0.coords).to(dev)
+
+    class Cfg(DataConfig):
+        resolution = (H, W)
+
+    infos = []
+    for b in range(B):
+        sb = synth_scene_boxes(K_, seed=40 + b)
+        names = ["ego"] + [DataConfig.class_names[int(c) - 1] for c in sb[:, 7]]
+        infos.append(dict(gt_boxes=np.concatenate([np.zeros((1, 7)), sb[:, :7].astype(np.float64)]),
+                          gt_names=names, gt_fut_trajs=synth_temporal_inputs(50 + b, K=K_)[0]))
+    ds = CustomDataset([dict(d) for d in infos], cfg=Cfg())
+    batch = ds.collate_fn([ds[i] for i in range(B)])
+    batch["gt_fut_trajs"] = [d["gt_fut_trajs"] for d in infos]
+
+    def run():
+        rng = [torch.Generator().manual_seed(90 + i) for i in range(B)]
+        return T.generate_sequence(ddpm, auto, lu, dict(batch), num_frames=3, num_steps=3,
+                                   mode="ddpm", traj_length=6, rng=rng, data_cfg=Cfg())
+
+    frames, points = run()
+    frames2, _ = run()
+    assert len(frames) == 3 and all(f.shape == (B, 5, H, W) for f in frames)
+    assert all(torch.isfinite(f).all() for f in frames)
+    assert all(torch.equal(a, b) for a, b in zip(frames, frames2))
+    assert not torch.equal(frames[1], frames[2])
+    assert points[1][0].shape == (H * W, 4)
+
+
+def test_condition_caches_follow_the_condition(dev):
+    """Step-invariant condition operands are cached per sampling run.  A second run whose condition
+    tensors land on the addresses the first run freed (caching allocator) must not see the first
+    run's operands: sample(A); sample(B) == a fresh model's sample(B)."""
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    def fresh():
+        m, e = build_cond_pair((8, 64), 8, 32)
+        return CondContinuousTimeGaussianDiffusion(m, e, cond_mode="concat").eval().to(dev)
+
+    def run(ddpm, seed):
+        batch = {k: v.to(dev) for k, v in synth_layout_batch(2, 8, 64, seed=seed).items()}
+        rng = [torch.Generator().manual_seed(5 + i) for i in range(2)]
+        return ddpm.sample(batch, 2, 4, progress=False, rng=rng, mode="ddim").cpu()
+
+    a = fresh()
+    run(a, 71)
+    second = run(a, 72)
+    assert torch.equal(second, run(fresh(), 72))
+    assert not torch.equal(second, run(fresh(), 71))
