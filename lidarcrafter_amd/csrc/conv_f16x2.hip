@@ -15,6 +15,8 @@
 //   input   : stays fp32 NCHW in HBM; the staging pass loads 8 channel planes per pixel
 //             (coalesced along W), splits, and writes [cb][row][col] 16-byte units into LDS.
 // Reference semantics: ops.Conv2d + ops.Pad, lidargen/models/unets/ops.py:32-49,149-173.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -41,7 +43,9 @@ struct ConvArgsH {
     // Cgn channels per sample (>= Ci rounded up to 16, zero rows beyond Ci); NULL = plain input
     const f32x4* gn;
     int Cgn, gn_silu;
-    int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles along W of one row band
+    int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles of one sample
+    int vert;  // 1: the block walks its tpb tiles down H (W-neighbours run concurrently), 0: along W
+    int xcd;   // 1: blockIdx.x is remapped so that each XCD owns a contiguous range of tiles
 };
 
 constexpr int GN_MAX_C = 1024;   // LDS table of fused GroupNorm rows: 16 KB
@@ -309,18 +313,32 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave / C::WPX_, wpx = wave % C::WPX_;
 
-    // persistent over `tpb` consecutive tiles along W (same sample, same row band): the next
-    // tile's first chunk is prefetched under the last chunk of the current tile and the epilogue
-    // stores drain under the next tile's MFMAs, so the per-block prologue / epilogue cost
-    // (~10 us of the 85 us of a 64->64 @32x1024 launch) is paid once per `tpb` tiles.
+    // Persistent over `tpb` consecutive tiles of one sample: the next tile's first chunk is
+    // prefetched under the last chunk of the current tile and the epilogue stores drain under the
+    // next tile's MFMAs, so the per-block prologue / epilogue cost (~10 us of the 85 us of a
+    // 64->64 @32x1024 launch) is paid once per `tpb` tiles.
+    // HBM-side reads of x are what bounds the wide levels (PMC: 185 MB fetched for a 67 MB input
+    // with W-walking blocks dealt round-robin to the XCDs: each 66-float row segment touches 4
+    // 128-byte lines, each 4-row tile re-reads 2 halo rows, and neighbours sit in other L2s).
+    // With `vert` the block walks DOWN H and with `xcd` each XCD owns a contiguous range of
+    // (sample, row group, W tile) ids, so at any time an XCD works on complete image rows of one
+    // sample: the line overlaps of W-neighbours hit in its L2.
     const int tpb = a.tpb;
-    const int groups_w = a.tiles_w / tpb;
     int bx = blockIdx.x;
-    const int tw_g = bx % groups_w; bx /= groups_w;
-    const int th_i = bx % a.tiles_h; bx /= a.tiles_h;
+    if (a.xcd) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    int tw_i, th_i;
+    if (a.vert) {
+        const int gh_ = a.tiles_h / tpb;
+        tw_i = bx % a.tiles_w; bx /= a.tiles_w;
+        th_i = (bx % gh_) * tpb; bx /= gh_;
+    } else {
+        const int gw_ = a.tiles_w / tpb;
+        tw_i = (bx % gw_) * tpb; bx /= gw_;
+        th_i = bx % a.tiles_h; bx /= a.tiles_h;
+    }
     const int b = bx;
-    const int h0 = th_i * C::TH_;
-    int w0 = tw_g * tpb * C::TW_;                     // first tile of the block
+    int h0 = th_i * C::TH_, w0 = tw_i * C::TW_;        // first tile of the block
+    const int dh = a.vert ? C::TH_ : 0, dw = a.vert ? 0 : C::TW_;
     const int co0 = blockIdx.y * BN;
     const int H = a.H, W = a.W;
     const int HW = H * W;
@@ -328,29 +346,30 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const unsigned nbytes = (unsigned)a.Ci * (unsigned)HW * 4u;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, nbytes, 0x00020000);
 
-    unsigned x_row[NXU];   // byte offset of (channel-block cb, row) in the sample, OOB marker = pad
-    int x_col[NXU];        // column of the unit inside the staged row
-    unsigned x_voff[NXU];  // x_row + 4 * (wrapped image column) for the CURRENT tile
+    int x_rc[NXU];         // (row << 16 | column) of the unit inside the staged tile
+    int x_cb8[NXU];        // 8 * channel-block of the unit, or -1 for padding units (CURRENT tile)
+    unsigned x_voff[NXU];  // byte offset of the unit's first channel in the sample, OOB marker = pad
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
         const int e = tid + i * NT;
         const int cb = e / (XR * XW);
         const int rem = e - cb * (XR * XW);
         const int r = rem / XW, c = rem - r * XW;
-        const int gh = h0 - HALO + r;
-        const bool ok = (e < XU) && gh >= 0 && gh < H;
-        x_row[i] = ok ? (unsigned)(cb * 8 * HW + gh * W) * 4u : 0xFFFFFFF0u;
-        x_col[i] = c;
+        x_rc[i] = e < XU ? ((cb << 28) | (r << 16) | c) : -1;
     }
-    auto set_voff = [&](int w0t) {
+    auto set_tile = [&](int h0t, int w0t) {
 #pragma unroll
         for (int i = 0; i < NXU; ++i) {
-            int gw = w0t - HALO + x_col[i];
+            const int cb = (x_rc[i] >> 28) & 7, r = (x_rc[i] >> 16) & 0xFFF, c = x_rc[i] & 0xFFFF;
+            const int gh = h0t - HALO + r;
+            int gw = w0t - HALO + c;
             gw %= W; if (gw < 0) gw += W;
-            x_voff[i] = x_row[i] == 0xFFFFFFF0u ? 0xFFFFFFF0u : x_row[i] + 4u * (unsigned)gw;
+            const bool ok = x_rc[i] >= 0 && gh >= 0 && gh < H;
+            x_voff[i] = ok ? (unsigned)(cb * 8 * HW + gh * W + gw) * 4u : 0xFFFFFFF0u;
+            x_cb8[i] = ok ? 8 * cb : -1;
         }
     };
-    set_voff(w0);
+    set_tile(h0, w0);
     long long w_idx[NWU];  // unit index of this thread's weight units for chunk 0
 #pragma unroll
     for (int i = 0; i < NWU; ++i) {
@@ -366,12 +385,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     if (use_gn) {
         const f32x4* g = a.gn + (long long)b * a.Cgn;
         for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
-    }
-    int x_cb8[NXU];        // 8 * channel-block of the unit, or -1 for padding units
-#pragma unroll
-    for (int i = 0; i < NXU; ++i) {
-        const int e = tid + i * NT;
-        x_cb8[i] = x_row[i] == 0xFFFFFFF0u ? -1 : 8 * (e / (XR * XW));
     }
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         for (int ch = 0; ch < last; ++ch) k_iter(ch, ch + 1);
         prefetch_res();          // the last chunk is peeled: no branch in the steady-state loop
         const bool more = tile + 1 < tpb;
-        if (more) set_voff(w0 + C::TW_);              // x offsets of the NEXT tile (uniform branch)
+        if (more) set_tile(h0 + dh, w0 + dw);         // x offsets of the NEXT tile (uniform branch)
         k_iter(last, more ? 0 : last);                // prefetches chunk 0 of the next tile
         // ---- epilogue of this tile: stores only (bias / residual already in registers) --------
 #pragma unroll
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
                 }
             }
         }
-        w0 += C::TW_;
+        h0 += dh; w0 += dw;
     }
 }
 
@@ -591,15 +604,29 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
     const int ncot = (a.Co + C::BN - 1) / C::BN;
-    int tpb = 1;   // up to 4 consecutive W tiles per block while every CU still gets a block
-    while (tpb < 4 && a.tiles_w % (tpb * 2) == 0 &&
-           (long long)a.B * a.tiles_h * (a.tiles_w / (tpb * 2)) * ncot >= 256)
-        tpb *= 2;
+    // up to 4 consecutive tiles per block while every CU still gets a block; walk down H when
+    // that allows as many tiles as walking along W (see the kernel header comment)
+    const long long n_tiles = (long long)a.B * a.tiles_h * a.tiles_w * ncot;
+    auto max_tpb = [&](int extent) {
+        int t = 1;
+        while (t < 4 && extent % (t * 2) == 0 && n_tiles / (t * 2) >= 256) t *= 2;
+        return t;
+    };
+    static const int vert_env = [] { const char* e = getenv("LC_CONV_VERT"); return e ? atoi(e) : 1; }();
+    static const int xcd_env = [] { const char* e = getenv("LC_CONV_XCD"); return e ? atoi(e) : 1; }();
+    const int tpb_h = max_tpb(a.tiles_h), tpb_w = max_tpb(a.tiles_w);
+    int vert = vert_env && tpb_h >= tpb_w;
+    int tpb = vert ? tpb_h : tpb_w;
     if (C::NTAP == 1) tpb = 1;   // 1x1: a chunk is 6 MFMAs per wave, block-level parallelism wins
-    if (a.tpb > 0) tpb = a.tpb;                          // explicit override (tests)
-    if (a.tiles_w % tpb) tpb = 1;
+    if (a.tpb > 0) {                                     // explicit override (tests): tpb*100 + cfg
+        tpb = a.tpb;
+        vert = vert_env && a.tiles_h % tpb == 0;
+        if (!vert && a.tiles_w % tpb) tpb = 1;
+    }
     a.tpb = tpb;
-    dim3 grid(a.B * a.tiles_h * (a.tiles_w / tpb), ncot);
+    a.vert = vert;
+    dim3 grid(a.B * a.tiles_h * a.tiles_w / tpb, ncot);
+    a.xcd = (xcd_env && grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
     hipLaunchKernelGGL(conv_f16x2_pipe_kernel<C>, grid, dim3(C::NT), 0, st, a);
     return lc_launch_status();
 }
