@@ -78,6 +78,54 @@ def cond(dev, B, steps):
             "layout_encoder_ms_once_per_batch": round(t_enc * 1e3, 2)}
 
 
+def sequence(dev, B, frames, steps):
+    """C4-shaped run at 32x1024: frame 0 with nuscenes-box-layout-v6, frames 1.. with
+    nuscenes-auto-reg-v2 (DDPM), the temporal glue resident on the device."""
+    import numpy as np
+    from lidarcrafter_amd.testing import seeded_fill, synth_scene_boxes, synth_temporal_inputs
+    from lidargen.dataset.custom_dataset import CustomDataset, DataConfig
+    from lidargen.utils import inference, temporal
+    from lidargen.utils.configs import __all__ as C
+
+    def build(name, s0):
+        ddpm, model, lu = inference.load_model_duffusion_training(C[name]())
+        seeded_fill(model, salt=s0), seeded_fill(ddpm.condition_model, salt=s0 + 1)
+        return ddpm.eval().to(dev), lu.to(dev)
+
+    ddpm, lu = build("nuscenes-box-layout-v6", 200)
+    auto, _ = build("nuscenes-auto-reg-v2", 300)
+    K_ = 6
+    infos = []
+    for b in range(B):
+        sb = synth_scene_boxes(K_, seed=40 + b)
+        names = ["ego"] + [DataConfig.class_names[int(c) - 1] for c in sb[:, 7]]
+        infos.append(dict(gt_boxes=np.concatenate([np.zeros((1, 7)), sb[:, :7].astype(np.float64)]),
+                          gt_names=names, gt_fut_trajs=synth_temporal_inputs(50 + b, K=K_)[0]))
+    ds = CustomDataset([dict(d) for d in infos])
+    batch = ds.collate_fn([ds[i] for i in range(B)])
+    batch["gt_fut_trajs"] = [d["gt_fut_trajs"] for d in infos]
+
+    def run(nf, ns):
+        rng = [torch.Generator().manual_seed(90 + i) for i in range(B)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fr, _ = temporal.generate_sequence(ddpm, auto, lu, dict(batch), num_frames=nf, num_steps=ns,
+                                           mode="ddpm", traj_length=16, rng=rng)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(f).all() for f in fr)
+        return time.perf_counter() - t0
+
+    run(2, 4)                                        # warm (weight packs, graphs, allocator)
+    t_full = run(frames, steps)
+    t_glue = run(frames, 3) - 0.0                    # 3 steps per frame: mostly glue + launch cost
+    per_step = (t_full - t_glue) / (frames * (steps - 3))
+    return {"batch": B, "frames": frames, "steps_per_frame": steps, "mode": "ddpm",
+            "seconds": round(t_full, 3), "ms_per_denoising_step": round(per_step * 1e3, 3),
+            "glue_ms_per_frame_upper_bound": round((t_glue - 3 * frames * per_step) / frames * 1e3, 2),
+            "note": "glue = projection, box rasterisation, transforms, points-in-boxes, compaction, "
+                    "CustomDataset item + collate, RNG draws on the host for DDPM noise"}
+
+
 def projection(dev, N):
     from lidarcrafter_amd import ops as K
     from lidarcrafter_amd.testing import synth_points
@@ -115,6 +163,7 @@ def main():
     out["cond_layout_v6_32x1024"] = [cond(dev, B, 10) for B in ((8,) if args.quick else (1, 8))]
     if not args.quick:
         out["uncond_64x2048"] = [uncond(dev, 4, (64, 2048), 6, "uncond64")]
+    out["temporal_sequence_32x1024"] = [sequence(dev, 2, 5, 16 if args.quick else 32)]
     out["projection"] = [projection(dev, N) for N in (34720, 131072, 1 << 22)]
     out["points_in_boxes_mask"] = [pib(dev, N, nb) for N, nb in ((34720, 13), (1 << 22, 13))]
     print(json.dumps(out, indent=1))
