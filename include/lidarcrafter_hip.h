@@ -280,6 +280,21 @@ int64_t lc_compact_scratch_elems(int N);
 int lc_compact_points(const float* rows, const int32_t* keep, int N, int keep_if_zero, float* out,
                       int32_t* src_index, int32_t* count, int32_t* scratch, lc_stream_t s);
 
+/* ---------------------------------------------------------------------------------------------
+ * BEV metrics front-end, lidargen/metrics/bev.py (SURVEY.md section 8f-3 ii):
+ *  lc_bev_histogram: point_cloud_to_histogram :5-24 -- rows with min_depth < |xyz| < max_depth are
+ *    binned by (x, y) into hist[bx*bins + by] with torch.histogramdd's rule (edges [bins+1] as
+ *    torch computes them, e[b] <= v < e[b+1], last bin right-inclusive); scratch = bins*bins int32.
+ *  lc_rbf_kernel_sum: partials[] (lc_rbf_partials_elems doubles) whose sum is
+ *    sum_ij exp(-gamma |p_i - q_j|^2), p [M,D], q [Mq,D] -- cdist_rbf(...).mean() * M * Mq of
+ *    compute_mmd_2d :47-55.
+ * ------------------------------------------------------------------------------------------- */
+int lc_bev_histogram(const float* pts, int pt_stride, int N, const float* edges, int bins,
+                     float min_depth, float max_depth, float* hist, int32_t* scratch, lc_stream_t s);
+int64_t lc_rbf_partials_elems(int M, int Mq);
+int lc_rbf_kernel_sum(const float* p, const float* q, int M, int Mq, int D, float gamma,
+                      double* partials, lc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

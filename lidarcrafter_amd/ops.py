@@ -537,6 +537,46 @@ def compact_points(rows: torch.Tensor, keep: torch.Tensor, keep_if_zero: bool = 
     return (out[:n], idx[:n]) if return_index else out[:n]
 
 
+# ------------------------------------------------------------------------------------ BEV metrics
+_hist_edges = {}
+
+
+def bev_histogram(points: torch.Tensor, field_size: float = 160.0, bins: int = 100,
+                  min_depth: float = 3.0, max_depth: float = 70.0) -> torch.Tensor:
+    """[N, >=3] device points -> float32 [bins, bins] counts of (x, y), torch.histogramdd rule
+    (lidargen/metrics/bev.py:5-24).  The bin edges are the ones torch itself computes."""
+    _req(points, "points")
+    if points.dim() != 2 or points.shape[1] < 3 or not points.is_contiguous():
+        raise ValueError("bev_histogram: points must be contiguous [N, >=3]")
+    bound = field_size / 2
+    key = (float(bound), int(bins), points.device)
+    e = _hist_edges.get(key)
+    if e is None:
+        e = torch.histogramdd(torch.empty(0, 2), bins=bins,
+                              range=[-bound, bound, -bound, bound]).bin_edges[0]
+        e = e.float().contiguous().to(points.device)
+        _hist_edges[key] = e
+    hist = torch.empty((bins, bins), device=points.device, dtype=_F32)
+    scratch = torch.empty((bins * bins,), device=points.device, dtype=torch.int32)
+    check(lib().lc_bev_histogram(points.data_ptr(), points.shape[1], points.shape[0], e.data_ptr(),
+                                 bins, float(min_depth), float(max_depth), hist.data_ptr(),
+                                 scratch.data_ptr(), _stream()), "lc_bev_histogram")
+    return hist
+
+
+def rbf_kernel_mean(p: torch.Tensor, q: torch.Tensor, sigma: float = 0.5) -> torch.Tensor:
+    """mean_ij exp(-|p_i - q_j|^2 / (2 sigma^2)) as a 0-d float64 device tensor (bev.py:27-34)."""
+    _req(p, "p"), _req(q, "q")
+    if p.dim() != 2 or q.dim() != 2 or p.shape[1] != q.shape[1] or not p.is_contiguous() or \
+            not q.is_contiguous():
+        raise ValueError("rbf_kernel_mean: p [M,D] and q [Mq,D] contiguous")
+    M, Mq, D = p.shape[0], q.shape[0], p.shape[1]
+    part = torch.empty((lib().lc_rbf_partials_elems(M, Mq),), device=p.device, dtype=torch.float64)
+    check(lib().lc_rbf_kernel_sum(p.data_ptr(), q.data_ptr(), M, Mq, D, 1.0 / (2.0 * sigma ** 2),
+                                  part.data_ptr(), _stream()), "lc_rbf_kernel_sum")
+    return part.sum() / (M * Mq)
+
+
 def roiaware_pool3d_forward(rois, pts, pts_feature, out_size, max_pts_each_voxel: int, method: int):
     """-> (pooled [N,X,Y,Z,C], pts_idx_of_voxels int32 [N,X,Y,Z,max_pts], argmax int32 [N,X,Y,Z,C])."""
     for n_, t_ in (("rois", rois), ("pts", pts), ("pts_feature", pts_feature)):

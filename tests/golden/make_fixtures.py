@@ -341,6 +341,35 @@ def sec_temporal():
     save("temporal", **out)
 
 
+def sec_bev():
+    """lidargen/metrics/bev.py (torch + scipy only: imported by file path): histograms of seeded
+    sweeps, the bin edges torch.histogramdd used, JSD / MMD between two sets of sweeps."""
+    import importlib.util
+    from lidarcrafter_amd.testing import synth_points
+
+    spec = importlib.util.spec_from_file_location("ref_bev", R.REF + "/lidargen/metrics/bev.py")
+    bev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bev)
+    sets = []
+    for base, scale in ((0, 1.0), (100, 0.8)):
+        hs = []
+        for i in range(5):
+            pts = synth_points(6000, seed=base + i)[:, :3] * np.float32(scale)
+            if i == 0:
+                pts[:7, 0] = [80.0, -80.0, 79.99999, 0.0, 1.6, -1.6, 80.00001]   # edges of the range
+                pts[:7, 1] = [0.5, 0.5, 0.5, 80.0, 0.0, 0.0, 0.5]
+                pts[:7, 2] = 0.0
+            hs.append(bev.point_cloud_to_histogram(torch.from_numpy(pts)))
+        sets.append(torch.stack(hs))
+    e = torch.histogramdd(torch.empty(0, 2), bins=100, range=[-80.0, 80.0, -80.0, 80.0]).bin_edges[0]
+    small = bev.point_cloud_to_histogram(torch.from_numpy(synth_points(3000, seed=5)[:, :3] * np.float32(0.02)),
+                                         min_depth=1e-6, max_depth=1e3, field_size=2.0)
+    save("bev", hist_a=sets[0].numpy().astype(np.uint16), hist_b=sets[1].numpy().astype(np.uint16),
+         edges=e.numpy(), hist_small=small.numpy().astype(np.uint16),
+         jsd=np.float64(bev.compute_jsd_2d(sets[0], sets[1])),
+         mmd=np.float64(bev.compute_mmd_2d(sets[0], sets[1])))
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":

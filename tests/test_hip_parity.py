@@ -819,3 +819,36 @@ def test_condition_caches_follow_the_condition(dev):
     second = run(a, 72)
     assert torch.equal(second, run(fresh(), 72))
     assert not torch.equal(second, run(fresh(), 71))
+
+
+# ------------------------------------------------------------------------------------- BEV metrics
+def test_bev_metrics_vs_reference_golden(dev, golden):
+    """lidargen.metrics.bev on the device vs the reference's own bev.py outputs: histogram counts
+    bit-exact (incl. points on the range edges), JSD / MMD to 1e-6."""
+    import lidargen  # noqa: F401
+    from lidargen.metrics import bev
+    from oracle import metrics as OM
+    from tests.test_oracle_vs_golden import _bev_clouds
+
+    g = golden("bev")
+    hs = []
+    for cl, key in zip(_bev_clouds(), ("hist_a", "hist_b")):
+        h = torch.stack([bev.point_cloud_to_histogram(torch.from_numpy(p).to(dev)) for p in cl])
+        assert np.array_equal(h.cpu().numpy(), g[key].astype(np.float32)), key
+        hs.append(h)
+    small = bev.point_cloud_to_histogram(
+        torch.from_numpy(synth_points(3000, seed=5)[:, :3] * np.float32(0.02)).to(dev),
+        min_depth=1e-6, max_depth=1e3, field_size=2.0)
+    assert np.array_equal(small.cpu().numpy(), g["hist_small"].astype(np.float32))
+    # [N,4] rows (the sampler's point format) bin like [N,3]
+    p4 = torch.from_numpy(synth_points(5000, seed=9)).to(dev)
+    assert torch.equal(bev.point_cloud_to_histogram(p4), bev.point_cloud_to_histogram(p4[:, :3].contiguous()))
+    assert abs(bev.compute_jsd_2d(hs[0], hs[1]) - float(g["jsd"])) < 1e-6
+    assert abs(bev.compute_mmd_2d(hs[0], hs[1]) - float(g["mmd"])) < 1e-6
+    # ragged pair counts (M, Mq not multiples of the 16 x 16 pair tile) against the float64 oracle
+    a = torch.rand(37, 300, device=dev)
+    b = torch.rand(21, 300, device=dev)
+    a, b = a / a.sum(1, keepdim=True), b / b.sum(1, keepdim=True)
+    ref = OM.compute_mmd_2d(a.cpu().numpy(), b.cpu().numpy())
+    got = (bev.cdist_rbf_mean(a, a) + bev.cdist_rbf_mean(b, b) - 2 * bev.cdist_rbf_mean(a, b)).item()
+    assert abs(got - ref) < 1e-9 + 1e-6 * abs(ref)
