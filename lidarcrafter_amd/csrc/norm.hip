@@ -7,19 +7,26 @@
 
 namespace {
 
-constexpr int GN_CHUNK = 16384;  // elements per stats block (64 KiB)
-
-__host__ __device__ inline int gn_chunks(long long n) { return (int)((n + GN_CHUNK - 1) / GN_CHUNK); }
+// elements per statistics block: 64 KiB normally, 16 KiB when the tensor is so small that 64 KiB
+// blocks would leave most CUs idle (deep levels at small batch: 128 blocks for [8,512,4,128])
+__host__ __device__ inline int gn_chunk_elems(int B, int G, long long n) {
+    const long long blocks = (long long)B * G * ((n + 16383) / 16384);
+    return blocks >= 512 ? 16384 : 4096;
+}
+__host__ __device__ inline int gn_chunks(int B, int G, long long n) {
+    const int ce = gn_chunk_elems(B, G, n);
+    return (int)((n + ce - 1) / ce);
+}
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long long x_bs,
                                                       double* __restrict__ part, int C, int G,
-                                                      long long HW, int nch) {
+                                                      long long HW, int nch, int chunk_elems) {
     const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int cpg = C / G;
     const long long n = (long long)cpg * HW;
     const float* p = x + b * x_bs + (long long)g * n;
-    const long long lo = (long long)chunk * GN_CHUNK;
-    const long long hi = (lo + GN_CHUNK < n) ? lo + GN_CHUNK : n;
+    const long long lo = (long long)chunk * chunk_elems;
+    const long long hi = (lo + chunk_elems < n) ? lo + chunk_elems : n;
     // shifted sums (pivot = first element of the group) -> no cancellation in E[d^2]-E[d]^2
     const float piv = p[0];
     float s = 0.f, q = 0.f;
@@ -48,14 +55,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
-// one block per (b, c, slab of the H*W plane)
+// one block per (b, cpb channels of one group, slab of the H*W plane)
 __global__ __launch_bounds__(256) void gn_apply_kernel(
     const float* __restrict__ x, long long x_bs, const double* __restrict__ part,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
     const float* __restrict__ shift, long long ss_bs, float* __restrict__ y, long long y_bs, int C,
-    int G, long long HW, int nch, float eps, int act) {
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int cpg = C / G, g = c / cpg;
+    int G, long long HW, int nch, float eps, int act, int cpb) {
+    const int c_first = blockIdx.y * cpb, b = blockIdx.z;     // cpb channels of ONE group per block
+    const int cpg = C / G, g = c_first / cpg;
     const double* pp = part + ((long long)b * G + g) * nch * 2;
     double s = 0.0, q = 0.0;
     for (int i = 0; i < nch; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
@@ -65,30 +72,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mu = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
-    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-    const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
-    const float sh = shift ? shift[b * ss_bs + c] : 0.0f;
-    const float* xp = x + b * x_bs + (long long)c * HW;
-    float* yp = y + b * y_bs + (long long)c * HW;
     const long long per = (HW + gridDim.x - 1) / gridDim.x;
     const long long lo = blockIdx.x * per;
     const long long hi = lo + per < HW ? lo + per : HW;
-    auto f = [&](float v) {
-        float t = (v - mu) * rstd;
-        t = t * ga + be;
-        t = t * sc + sh;
-        return act ? lc_silu(t) : t;
-    };
-    const bool vec = (HW & 3) == 0 && (per & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0;
-    if (vec) {
-        for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
-            v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
-            *reinterpret_cast<f32x4*>(yp + i) = v;
+    for (int c = c_first; c < c_first + cpb; ++c) {
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+        const float sh = shift ? shift[b * ss_bs + c] : 0.0f;
+        const float* xp = x + b * x_bs + (long long)c * HW;
+        float* yp = y + b * y_bs + (long long)c * HW;
+        auto f = [&](float v) {
+            float t = (v - mu) * rstd;
+            t = t * ga + be;
+            t = t * sc + sh;
+            return act ? lc_silu(t) : t;
+        };
+        const bool vec = (HW & 3) == 0 && (per & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0;
+        if (vec) {
+            for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
+                v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+                *reinterpret_cast<f32x4*>(yp + i) = v;
+            }
+        } else {
+            for (long long i = lo + threadIdx.x; i < hi; i += 256) yp[i] = f(xp[i]);
         }
-    } else {
-        for (long long i = lo + threadIdx.x; i < hi; i += 256) yp[i] = f(xp[i]);
     }
 }
 
@@ -132,7 +141,7 @@ extern "C" int lc_groupnorm_coeffs(const float* x, int64_t x_bs, const double* p
                                    int Cpad, int H, int W, int G, float eps, lc_stream_t s) {
     if (!x || !partials || !coeffs || B <= 0 || G <= 0 || C % G || Cpad < C) return LC_EINVAL;
     const long long HW = (long long)H * W;
-    const int nch = gn_chunks((long long)(C / G) * HW);
+    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
     const int n = B * Cpad;
     hipLaunchKernelGGL(gn_coeffs_kernel, dim3((n + 255) / 256), dim3(256), 0, lc_s(s), partials, x,
                        (long long)x_bs, gamma, beta, scale, shift, (long long)ss_bs,
@@ -142,16 +151,16 @@ extern "C" int lc_groupnorm_coeffs(const float* x, int64_t x_bs, const double* p
 
 extern "C" int64_t lc_groupnorm_partials_elems(int B, int C, int H, int W, int G) {
     if (G <= 0 || C % G) return 0;
-    return (int64_t)B * G * gn_chunks((long long)(C / G) * H * W) * 2;
+    return (int64_t)B * G * gn_chunks(B, G, (long long)(C / G) * H * W) * 2;
 }
 
 extern "C" int lc_groupnorm_stats(const float* x, int64_t x_bs, double* partials, int B, int C,
                                   int H, int W, int G, lc_stream_t s) {
     if (!x || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const long long HW = (long long)H * W;
-    const int nch = gn_chunks((long long)(C / G) * HW);
+    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, G, B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
-                       partials, C, G, HW, nch);
+                       partials, C, G, HW, nch, gn_chunk_elems(B, G, (long long)(C / G) * HW));
     return lc_launch_status();
 }
 
@@ -162,11 +171,18 @@ extern "C" int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* pa
                                   lc_stream_t s) {
     if (!x || !y || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const long long HW = (long long)H * W;
-    const int nch = gn_chunks((long long)(C / G) * HW);
+    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
     int slabs = (int)((HW + 4095) / 4096);  // >= 4096 elements per block
     if (slabs < 1) slabs = 1;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C, B), dim3(256), 0, lc_s(s), x,
+    // small planes: several channels of a group per block, so the per-block fold of the partials
+    // (fp64 divide + sqrt) is paid once per >= 4096 elements while >= 512 blocks remain
+    int cpb = 1;
+    const int cpg = C / G;
+    while (cpb * 2 <= cpg && cpg % (cpb * 2) == 0 && HW * cpb * 2 <= 4096 &&
+           (long long)B * (C / (cpb * 2)) * slabs >= 512)
+        cpb *= 2;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
                        (long long)x_bs, partials, gamma, beta, scale, shift, (long long)ss_bs, y,
-                       (long long)y_bs, C, G, HW, nch, eps, act_silu);
+                       (long long)y_bs, C, G, HW, nch, eps, act_silu, cpb);
     return lc_launch_status();
 }

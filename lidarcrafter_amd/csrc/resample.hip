@@ -10,6 +10,7 @@ namespace {
 
 #pragma clang fp contract(off)
 
+// Scalar form (any even H, W): 16 strided loads per output.
 __global__ __launch_bounds__(256) void down2_kernel(const float* __restrict__ x, long long x_bs,
                                                    float* __restrict__ y, long long y_bs, int C,
                                                    int H, int W) {
@@ -43,6 +44,51 @@ __global__ __launch_bounds__(256) void down2_kernel(const float* __restrict__ x,
             acc += k[a] * hz;
         }
         yb[e] = acc;
+    }
+}
+
+// Vector form (W % 256 == 0, 16-byte aligned rows): a wave covers 256 consecutive input columns
+// of one (channel, output row); lane l loads the aligned float4 x[4l .. 4l+3] of each of the 4
+// input rows and takes x[4l-1] / x[4l+4] from its neighbours with two DPP-class shuffles (the
+// ring wrap is a scalar load only at the two ends of the 256-column segment) -> 2 outputs per
+// lane, 4 vector loads instead of 32 scalar ones.  Same arithmetic order as the scalar form.
+__global__ __launch_bounds__(256) void down2_vec_kernel(const float* __restrict__ x, long long x_bs,
+                                                       float* __restrict__ y, long long y_bs, int C,
+                                                       int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int segs = W / 256;                                  // 256-column segments per row
+    const long long n_items = (long long)C * Ho * segs;        // one wave each
+    const int b = blockIdx.y;
+    const float* xb = x + b * x_bs;
+    float* yb = y + b * y_bs;
+    const int lane = threadIdx.x & 63;
+    const float k[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    for (long long it = blockIdx.x * 4ll + (threadIdx.x >> 6); it < n_items; it += (long long)gridDim.x * 4) {
+        const int sg = it % segs;
+        const long long r = it / segs;
+        const int i = r % Ho;
+        const int c = r / Ho;
+        const float* xc = xb + (long long)c * H * W;
+        const int w0 = sg * 256 + 4 * lane;
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int h = 2 * i + a - 1;
+            float hz0 = 0.f, hz1 = 0.f;
+            if (h >= 0 && h < H) {                             // uniform per wave
+                const float* row = xc + (long long)h * W;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + w0);
+                float left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
+                if (lane == 0) left = row[w0 == 0 ? W - 1 : w0 - 1];
+                if (lane == 63) right = row[w0 + 4 == W ? 0 : w0 + 4];
+                hz0 = ((k[0] * left + k[1] * v.x) + k[2] * v.y) + k[3] * v.z;
+                hz1 = ((k[0] * v.y + k[1] * v.z) + k[2] * v.w) + k[3] * right;
+            }
+            acc0 += k[a] * hz0;
+            acc1 += k[a] * hz1;
+        }
+        float2 o; o.x = acc0; o.y = acc1;
+        *reinterpret_cast<float2*>(yb + ((long long)c * Ho + i) * Wo + w0 / 2) = o;
     }
 }
 
@@ -94,6 +140,16 @@ extern "C" int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t
     if (dir < 0) {
         if ((H & 1) || (W & 1)) return LC_EUNSUP;
         const long long total = (long long)C * (H / 2) * (W / 2);
+        const bool vec = W % 256 == 0 && (x_bs & 3) == 0 && (y_bs & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(y) & 7) == 0;
+        if (vec) {
+            const long long items = (long long)C * (H / 2) * (W / 256);
+            int blocks = (int)((items + 3) / 4 > 16384 ? 16384 : (items + 3) / 4);
+            hipLaunchKernelGGL(down2_vec_kernel, dim3(blocks, B), dim3(256), 0, lc_s(s), x,
+                               (long long)x_bs, y, (long long)y_bs, C, H, W);
+            return lc_launch_status();
+        }
         int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
         hipLaunchKernelGGL(down2_kernel, dim3(blocks, B), dim3(256), 0, lc_s(s), x, (long long)x_bs, y,
                            (long long)y_bs, C, H, W);

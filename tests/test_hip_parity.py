@@ -125,7 +125,8 @@ def test_conv_golden(dev, golden):
 
 # ------------------------------------------------------------------------------------- norm
 @pytest.mark.parametrize("B,C,H,W,G", [(2, 16, 4, 8, 8), (2, 64, 32, 1024, 8), (1, 512, 4, 128, 8),
-                                       (2, 256, 8, 256, 32), (3, 48, 1, 8, 8), (2, 96, 3, 5, 32)])
+                                       (2, 256, 8, 256, 32), (3, 48, 1, 8, 8), (2, 96, 3, 5, 32),
+                                       (8, 512, 4, 128, 8), (8, 256, 8, 256, 8), (8, 384, 4, 128, 32)])
 @pytest.mark.parametrize("mode", ["affine", "ada", "plain"])
 def test_groupnorm(dev, B, C, H, W, G, mode):
     from lidarcrafter_amd import ops as K
@@ -162,7 +163,8 @@ def test_groupnorm_large_mean(dev):
 
 
 # ------------------------------------------------------------------------------------- resample
-@pytest.mark.parametrize("B,C,H,W", [(2, 3, 4, 16), (1, 128, 32, 1024), (2, 64, 2, 8), (2, 7, 6, 10)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 4, 16), (1, 128, 32, 1024), (2, 64, 2, 8), (2, 7, 6, 10),
+                                     (2, 5, 6, 256), (1, 4, 8, 512)])
 def test_resample(dev, B, C, H, W, golden):
     from lidarcrafter_amd import ops as K
     from oracle import denoiser as D
