@@ -75,11 +75,12 @@ class HipLibraryMissing(RuntimeError):
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
+        path = os.environ.get("LC_HIP_LIB", LIB)   # developer override: A/B a differently built library
+        if not os.path.exists(path):
             raise HipLibraryMissing(
-                f"{LIB} not found: run `python -m lidarcrafter_amd.build` "
+                f"{path} not found: run `python -m lidarcrafter_amd.build` "
                 "(or __graft_entry__.build()). There is no CPU fallback for the hot path.")
-        handle = C.CDLL(LIB)
+        handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
