@@ -31,7 +31,9 @@ def test_library_exports_every_symbol():
     # pure host-side helpers are callable without a GPU
     assert handle.lc_packed_conv_weight_elems(2, 64, 3) == 9 * 64 * 64
     assert handle.lc_packed_conv_weight_elems(100, 42, 1) == 48 * 128
-    assert handle.lc_groupnorm_partials_elems(2, 64, 32, 1024, 8) == 2 * 8 * 16 * 2
+    # statistics blocks: 64 KiB chunks, 16 KiB when that would leave fewer than 512 blocks
+    assert handle.lc_groupnorm_partials_elems(32, 64, 32, 1024, 8) == 32 * 8 * 16 * 2
+    assert handle.lc_groupnorm_partials_elems(2, 64, 32, 1024, 8) == 2 * 8 * 64 * 2
 
 
 def test_no_cpu_fallback():
