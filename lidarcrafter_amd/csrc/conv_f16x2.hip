@@ -761,6 +761,13 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.tpb = 0;
     if (tile_cfg >= 100) { a.tpb = tile_cfg / 100; tile_cfg %= 100; }   // cfg = tpb*100 + tile id
     if (gn_coeffs && (gn_cpad < (Ci + 15) / 16 * 16 || gn_cpad > GN_MAX_C)) return LC_EINVAL;
+    // A 1x1 conv has no spatial structure: fold the contiguous H*W plane into rows of 64 pixels so
+    // that the 2-row tiles are fully used whatever the caller's aspect ratio is (a Conv1d over L
+    // tokens arrives as H = 1, W = L and would leave every second tile row empty).
+    if (ks == 1 && ((long long)H * W) % 128 == 0) {
+        a.H = H = (int)(((long long)H * W) / 64);
+        a.W = W = 64;
+    }
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
 }
