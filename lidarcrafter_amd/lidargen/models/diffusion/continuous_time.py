@@ -14,7 +14,7 @@ re-designed for the GPU:
 from __future__ import annotations
 
 import os
-from typing import List, Literal
+from typing import Literal
 
 import torch
 from torch import nn

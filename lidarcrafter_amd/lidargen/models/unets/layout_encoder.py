@@ -11,7 +11,6 @@ import math
 import torch
 import torch as th
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class LayerNorm(nn.LayerNorm):

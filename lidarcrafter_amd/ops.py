@@ -7,8 +7,6 @@ missing library raises.
 """
 from __future__ import annotations
 
-import math
-import weakref
 from typing import Optional
 
 import torch
