@@ -88,6 +88,81 @@ def sample(denoise, shape, num_steps, rng, *, mode="ddpm", ddim_eta=0.0, objecti
     return torch.stack(out) if return_all else x
 
 
+def q_step_from_x_0(x_0, steps, rng, schedule=log_snr_cosine):
+    """continuous_time.py:171-178: (x_t, noise) with x_t = alpha x_0 + sigma noise."""
+    noise = randn(tuple(x_0.shape), rng)
+    a, s = alpha_sigma(schedule(steps)[:, None, None, None])
+    return x_0 * a + noise * s, noise
+
+
+def q_step(x_s, step_t, step_s, rng, schedule=log_snr_cosine):
+    """continuous_time.py:180-193: q(z_t | z_s), 0 < s < t < 1."""
+    a_t, s_t = alpha_sigma(schedule(step_t)[:, None, None, None])
+    a_s, s_s = alpha_sigma(schedule(step_s)[:, None, None, None])
+    a_ts = a_t / a_s
+    var = s_t.pow(2) - a_ts.pow(2) * s_s.pow(2)
+    return x_s * a_ts + var.sqrt() * randn(tuple(x_s.shape), rng)
+
+
+@torch.no_grad()
+def repaint(denoise, known, mask, num_steps, num_resample_steps, jump_length, rng, *, shape,
+            return_all=False, schedule=log_snr_cosine):
+    """continuous_time.py:262-330 (RePaint): the draw order is x_T, then per inner step the
+    known-region noise (q_step_from_x_0) before the reverse step's noise, then the re-noising."""
+    B = known.shape[0]
+    x_t = randn(shape, rng)
+    steps = torch.linspace(1, 0, num_steps + 1)[None].repeat_interleave(B, 0)
+    out = [x_t]
+    x_s = x_t
+    for i in range(num_steps):
+        for j in range(num_resample_steps):
+            interp = torch.linspace(0, 1, jump_length + 1)
+            r = steps[:, [i]] + interp[None] * (steps[:, [i + 1]] - steps[:, [i]])
+            x = x_t
+            for k in range(jump_length):
+                known_s, _ = q_step_from_x_0(known, r[:, k + 1], rng, schedule)
+                noise = randn(tuple(x.shape), rng)
+                unknown_s = p_step(denoise, x, r[:, k], r[:, k + 1], noise, mode="ddpm",
+                                   schedule=schedule)
+                x = mask * known_s + (1 - mask) * unknown_s
+            x_s = x
+            out.append(x_s)
+            if i == num_steps - 1 or j == num_resample_steps - 1:
+                x_t = x
+                break
+            for k in range(jump_length, 0, -1):
+                x = q_step(x, r[:, k - 1], r[:, k], rng, schedule)
+            x_t = x
+    return torch.stack(out) if return_all else x_s
+
+
+def loss_weight(steps, objective, min_snr=True, gamma=5.0, schedule=log_snr_cosine):
+    """continuous_time.py:155-169."""
+    snr = schedule(steps).exp()
+    clipped = snr.clamp(max=gamma) if min_snr else snr.clone()
+    return {"eps": clipped / snr, "x_0": clipped, "v": clipped / (snr + 1)}[objective]
+
+
+@torch.no_grad()
+def p_loss(denoise, x_0, steps, noise_rng, objective="eps", loss_type="l2", min_snr=True,
+           schedule=log_snr_cosine):
+    """base.py:124-143 + continuous_time.py:140-153 (targets): masked mean of the per-pixel
+    criterion (mask = ones), weighted per sample."""
+    x_t, noise = q_step_from_x_0(x_0, steps, noise_rng, schedule)
+    lam = schedule(steps)
+    pred = denoise(x_t, lam)
+    a, s = alpha_sigma(lam[:, None, None, None])
+    target = {"eps": noise, "x_0": x_0, "v": a * noise - s * x_0}[objective]
+    crit = {"l2": torch.nn.MSELoss(reduction="none"), "l1": torch.nn.L1Loss(reduction="none"),
+            "huber": torch.nn.SmoothL1Loss(reduction="none")}[loss_type]
+    loss = crit(pred, target).flatten(1).sum(1, keepdim=True)
+    loss = loss / (torch.ones_like(x_0).flatten(1).sum(1, keepdim=True) + 1e-8)
+    # the reference multiplies loss [B,1] by a weight shaped [B,1,1,1]: the product broadcasts to
+    # [B,1,B,1], i.e. mean(loss) * mean(weight) -- kept as is (base.py:141-143)
+    w = loss_weight(steps, objective, min_snr, schedule=schedule)[:, None, None, None]
+    return (loss * w).mean()
+
+
 # ----------------------------------------------------------------------------- discrete time
 def beta_table(kind: str, T: int) -> torch.Tensor:
     """discrete_time.py:12-49 (fp64)."""

@@ -370,6 +370,45 @@ def sec_bev():
          mmd=np.float64(bev.compute_mmd_2d(sets[0], sets[1])))
 
 
+def sec_sampler_extras():
+    """The sampler entry points not covered by `diffusion` / `trajectory`: q_step_from_x_0, q_step,
+    RePaint (continuous_time.py:262-330), conditional inpaint (continuous_time_cond.py:283-353)
+    and the training-loss VALUE p_loss (base.py:124-143) for every objective / loss weighting the
+    reference offers, on the reduced models with seeded weights."""
+    eu = R.ref("models.unets.efficient_unet")
+    df = R.ref("models.diffusion")
+    out = {}
+    m = _build_uncond(eu, 16, (8, 64))
+    ddpm = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval()
+    x0 = seeded_randn(2, 2, 8, 64, seed=71).clamp(-1, 1)
+    steps = torch.tensor([0.8, 0.3])
+    rng = [torch.Generator().manual_seed(300 + i) for i in range(2)]
+    xt, noise = ddpm.q_step_from_x_0(x0, steps, rng=rng)
+    out["q0_xt"], out["q0_noise"] = xt, noise
+    rng = [torch.Generator().manual_seed(310 + i) for i in range(2)]
+    out["q_step"] = ddpm.q_step(xt, torch.tensor([0.9, 0.5]), steps, rng=rng)
+    mask = (seeded_randn(2, 1, 8, 64, seed=72) > 0).float().expand(-1, 2, -1, -1).contiguous()
+    out["mask"] = mask
+    with torch.no_grad():
+        rng = [torch.Generator().manual_seed(320 + i) for i in range(2)]
+        out["repaint"] = ddpm.repaint(x0, mask, num_steps=4, num_resample_steps=2, jump_length=2,
+                                      progress=False, rng=rng, return_all=True)
+        for obj, lt, msw in (("eps", "l2", True), ("v", "l2", True), ("x_0", "l2", True),
+                             ("eps", "l1", False), ("v", "huber", True)):
+            d2 = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity(), prediction_type=obj,
+                                                    loss_type=lt, min_snr_loss_weight=msw).eval()
+            torch.manual_seed(5)
+            out[f"loss_{obj}_{lt}_{int(msw)}"] = d2.p_loss(x0, steps)
+    mc, enc = _build_cond((8, 64), 8, 32)
+    dc = df.CondContinuousTimeGaussianDiffusion(mc, enc, cond_mode="concat").eval()
+    batch = synth_layout_batch(2, 8, 64, seed=73)
+    with torch.no_grad():
+        rng = [torch.Generator().manual_seed(330 + i) for i in range(2)]
+        out["inpaint"] = dc.inpaint(x0, mask, batch, num_steps=3, num_resample_steps=1, jump_length=2,
+                                    progress=False, rng=rng, return_all=True)
+    save("sampler_extras", **out)
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":
