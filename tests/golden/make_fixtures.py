@@ -409,6 +409,24 @@ def sec_sampler_extras():
     save("sampler_extras", **out)
 
 
+def sec_schedules():
+    """The log-SNR schedule variants of continuous_time.py:18-58 (linear, cosine, shifted,
+    interpolated) as the reference evaluates them (float32 tensors, python-float constants)."""
+    ct = R.ref("models.diffusion.continuous_time")
+    t = torch.linspace(1.0, 0.0, 33)
+    out = {"t": t,
+           "linear": ct._log_snr_schedule_linear(t)[:, 0, 0, 0],
+           "cosine": ct._log_snr_schedule_cosine(t)[:, 0, 0, 0],
+           "cosine_m10_12": ct._log_snr_schedule_cosine(t, logsnr_min=-10, logsnr_max=12)[:, 0, 0, 0],
+           "shifted_64_32": ct._log_snr_schedule_cosine_shifted(t, 64, 32)[:, 0, 0, 0],
+           "shifted_32_128": ct._log_snr_schedule_cosine_shifted(t, 32, 128)[:, 0, 0, 0],
+           # the reference multiplies t [N] by a [N,1,1,1] tensor here, so for N > 1 it returns an
+           # [N,1,1,N] outer product (unusable for batches); evaluated one t at a time = the intent
+           "interp_64_32_256": torch.cat([ct._log_snr_schedule_cosine_interpolated(
+               t[i:i + 1], 64, 32, 256)[:, 0, 0, 0] for i in range(len(t))])}
+    save("schedules", **out)
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":
