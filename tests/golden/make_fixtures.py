@@ -427,6 +427,23 @@ def sec_schedules():
     save("schedules", **out)
 
 
+def sec_discrete_trajectory():
+    """DiscreteTimeGaussianDiffusion.sample (discrete_time.py:182-201) on the reduced UNet: all
+    states 0, 1, 25, 50 of a 50-step run (T = 50), ddpm and ddim."""
+    eu = R.ref("models.unets.efficient_unet")
+    df = R.ref("models.diffusion")
+    m = _build_uncond(eu, 16, (8, 64))
+    out = {}
+    for kind in ("linear", "cosine"):
+        dd = df.DiscreteTimeGaussianDiffusion(m, None, num_training_steps=50, noise_schedule=kind).eval()
+        for mode in ("ddpm", "ddim"):
+            rng = [torch.Generator().manual_seed(400 + i) for i in range(2)]
+            xs = dd.sample(2, 50, progress=False, rng=rng, return_all=True, mode=mode)
+            assert torch.isfinite(xs).all()
+            out[f"{kind}_{mode}"] = xs[[0, 1, 25, 50]]
+    save("discrete_trajectory", **out)
+
+
 SECTIONS = {k[4:]: v for k, v in list(globals().items()) if k.startswith("sec_")}
 
 if __name__ == "__main__":

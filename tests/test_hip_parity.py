@@ -921,3 +921,21 @@ def test_sampler_extras_golden(dev, golden):
     assert ip.shape == ref.shape and torch.equal(ip[0], ref[0])
     for i in range(1, ip.shape[0]):
         assert rel_l2(ip[i], ref[i]) < 1e-3, (i, rel_l2(ip[i], ref[i]))
+
+
+def test_discrete_time_sampler_golden(dev, golden):
+    """DiscreteTimeGaussianDiffusion.sample (integer timesteps into the same HIP denoiser) vs the
+    reference's states 0, 1, 25, 50 of a 50-step run (T = 50), both update rules, two beta schedules."""
+    from lidargen.models.diffusion import DiscreteTimeGaussianDiffusion
+
+    g = golden("discrete_trajectory")
+    m = _uncond(16, (8, 64), dev)
+    for kind in ("linear", "cosine"):
+        dd = DiscreteTimeGaussianDiffusion(m, None, num_training_steps=50, noise_schedule=kind).eval().to(dev)
+        for mode in ("ddpm", "ddim"):
+            rng = [torch.Generator().manual_seed(400 + i) for i in range(2)]
+            xs = dd.sample(2, 50, progress=False, rng=rng, return_all=True, mode=mode).cpu()[[0, 1, 25, 50]]
+            ref = T(g[f"{kind}_{mode}"])
+            assert torch.equal(xs[0], ref[0])
+            for i in range(1, 4):
+                assert rel_l2(xs[i], ref[i]) < 1e-3, (kind, mode, i, rel_l2(xs[i], ref[i]))
