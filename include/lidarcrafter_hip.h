@@ -67,12 +67,24 @@ int lc_conv2d_ring_fwd(const float* x, int64_t x_bs, const float* wp, const floa
 int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks);
 int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
                               lc_stream_t s);
+/* Input normalisation straight from the statistics (no lc_groupnorm_coeffs launch): the partials
+ * of lc_groupnorm_stats over the conv's input plus the GroupNorm / AdaGN parameters; every block
+ * derives the rows of its sample in its prologue with the arithmetic of lc_groupnorm_coeffs. */
+typedef struct lc_gn_stats_input {
+    const double* partials;   /* lc_groupnorm_stats(x, ...) of THIS conv's input */
+    int G, nch;               /* groups; chunks per group = partials_elems / (2 * B * G) */
+    float eps;
+    const float *gamma, *beta, *scale, *shift;   /* each may be NULL, as in lc_groupnorm_apply */
+    int64_t ss_bs;
+} lc_gn_stats_input;
+
 int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, const void* wp_lo,
                              const float* bias, const float* res, int64_t res_bs, float* y,
                              int64_t y_bs, int B, int Ci, int Co, int H, int W, int ks,
                              float out_scale, int tile_cfg /* 0 = auto */,
                              const float* gn_coeffs /* NULL or [B, gn_cpad, 4] */, int gn_cpad,
-                             int gn_silu, lc_stream_t s);
+                             int gn_silu, const lc_gn_stats_input* gn_stats /* NULL, or instead of
+                             gn_coeffs */, lc_stream_t s);
 /* Fused input normalisation: with gn_coeffs != NULL the kernel applies
  *   x <- silu?( (x - mu) * A + Bc )       rows (mu, A, Bc, 0) from lc_groupnorm_coeffs
  * while staging the input tile (the GN -> SiLU -> Conv chain of efficient_unet.py:101-108 and

@@ -17,6 +17,15 @@ class CmOperand(C.Structure):
 
 _op = C.POINTER(CmOperand)
 
+
+class GnStatsInput(C.Structure):
+    """struct lc_gn_stats_input: GroupNorm statistics + parameters for the conv's fused input norm."""
+    _fields_ = [("partials", vp), ("G", i32), ("nch", i32), ("eps", f32), ("gamma", vp), ("beta", vp),
+                ("scale", vp), ("shift", vp), ("ss_bs", i64)]
+
+
+_gs = C.POINTER(GnStatsInput)
+
 # name -> (restype, argtypes); mirrors include/lidarcrafter_hip.h one to one
 SIGNATURES = {
     "lc_abi_version": (i32, []),
@@ -28,7 +37,7 @@ SIGNATURES = {
     "lc_packed_conv_weight_f16x2_elems": (i64, [i32, i32, i32]),
     "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "lc_conv2d_ring_f16x2_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
-                                       i32, i32, f32, i32, vp, i32, i32, vp]),
+                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp]),
     "lc_groupnorm_coeffs": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, f32, vp]),
     "lc_groupnorm_partials_elems": (i64, [i32, i32, i32, i32, i32]),

@@ -46,12 +46,38 @@ struct ConvArgsH {
     // Cgn channels per sample (>= Ci rounded up to 16, zero rows beyond Ci); NULL = plain input
     const f32x4* gn;
     int Cgn, gn_silu;
+    // ... or the statistics themselves (lc_groupnorm_stats partials): the block derives the rows of
+    // its sample in its prologue, so no lc_groupnorm_coeffs launch sits between stats and conv
+    lc_gn_stats_input gs;
     int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles of one sample
     int vert;  // 1: the block walks its tpb tiles down H (W-neighbours run concurrently), 0: along W
     int xcd;   // 1: blockIdx.x is remapped so that each XCD owns a contiguous range of tiles
 };
 
 constexpr int GN_MAX_C = 1024;   // LDS table of fused GroupNorm rows: 16 KB
+
+// (mu, A, Bc, 0) of channel c of sample b from the statistics partials -- the arithmetic of
+// gn_coeffs_kernel (norm.hip), so both routes give bit-identical rows
+__device__ __forceinline__ f32x4 gn_row_from_stats(const lc_gn_stats_input& gs, const float* xb,
+                                                   int b, int c, int C, long long HW) {
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (c >= C) return r;
+    const int cpg = C / gs.G, g = c / cpg;
+    const double* pp = gs.partials + ((long long)b * gs.G + g) * gs.nch * 2;
+    double s_ = 0.0, q_ = 0.0;
+    for (int k = 0; k < gs.nch; ++k) { s_ += pp[2 * k]; q_ += pp[2 * k + 1]; }
+    const double n = (double)cpg * (double)HW;
+    const double dm = s_ / n;
+    double var = q_ / n - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)gs.eps));
+    const float mu = (float)((double)xb[(long long)g * cpg * HW] + dm);
+    const float ga = gs.gamma ? gs.gamma[c] : 1.0f, be = gs.beta ? gs.beta[c] : 0.0f;
+    const float sc = gs.scale ? 1.0f + gs.scale[b * gs.ss_bs + c] : 1.0f;
+    const float sh = gs.shift ? gs.shift[b * gs.ss_bs + c] : 0.0f;
+    r.x = mu; r.y = rstd * ga * sc; r.z = be * sc + sh;
+    return r;
+}
 
 __device__ __forceinline__ float gn_act(float x, const f32x4 c, int silu) {
     float y = fmaf(x - c.x, c.y, c.z);
@@ -200,8 +226,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
 
     const int nchunk = a.Cib / CB;
     if (a.gn) {
-        const f32x4* g = a.gn + (long long)b * a.Cgn;
-        for (int i = tid; i < a.Cgn; i += 256) ctab[i] = g[i];
+        if (a.gs.partials) {
+            for (int i = tid; i < a.Cgn; i += 256) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
+        } else {
+            const f32x4* g = a.gn + (long long)b * a.Cgn;
+            for (int i = tid; i < a.Cgn; i += 256) ctab[i] = g[i];
+        }
         __syncthreads();
     }
     load_chunk(0);
@@ -386,8 +416,12 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 
     const bool use_gn = a.gn != nullptr;
     if (use_gn) {
-        const f32x4* g = a.gn + (long long)b * a.Cgn;
-        for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
+        if (a.gs.partials) {
+            for (int i = tid; i < a.Cgn; i += NT) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
+        } else {
+            const f32x4* g = a.gn + (long long)b * a.Cgn;
+            for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
+        }
     }
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
@@ -744,7 +778,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
                                         int64_t res_bs, float* y, int64_t y_bs, int B, int Ci,
                                         int Co, int H, int W, int ks, float out_scale, int tile_cfg,
                                         const float* gn_coeffs, int gn_cpad, int gn_silu,
-                                        lc_stream_t s) {
+                                        const lc_gn_stats_input* gn_stats, lc_stream_t s) {
     if (!x || !wp_hi || !wp_lo || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0)
         return LC_EINVAL;
     if (ks != 1 && ks != 3) return LC_EUNSUP;
@@ -758,9 +792,18 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.tiles_h = a.tiles_w = 0;
     a.gn = reinterpret_cast<const f32x4*>(gn_coeffs);
     a.Cgn = gn_cpad; a.gn_silu = gn_silu;
+    a.gs = lc_gn_stats_input{nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0};
+    if (gn_stats) {
+        if (gn_coeffs || !gn_stats->partials || gn_stats->G <= 0 || Ci % gn_stats->G ||
+            gn_stats->nch <= 0)
+            return LC_EINVAL;
+        a.gs = *gn_stats;
+        a.gn = reinterpret_cast<const f32x4*>(x);   // non-null marker: "normalise the input"
+        a.Cgn = gn_cpad > 0 ? gn_cpad : (Ci + 15) / 16 * 16;
+    }
     a.tpb = 0;
     if (tile_cfg >= 100) { a.tpb = tile_cfg / 100; tile_cfg %= 100; }   // cfg = tpb*100 + tile id
-    if (gn_coeffs && (gn_cpad < (Ci + 15) / 16 * 16 || gn_cpad > GN_MAX_C)) return LC_EINVAL;
+    if (a.gn && (a.Cgn < (Ci + 15) / 16 * 16 || a.Cgn > GN_MAX_C)) return LC_EINVAL;
     // A 1x1 conv has no spatial structure: fold the contiguous H*W plane into rows of 64 pixels so
     // that the 2-row tiles are fully used whatever the caller's aspect ratio is (a Conv1d over L
     // tokens arrives as H = 1, W = L and would leave every second tile row empty).

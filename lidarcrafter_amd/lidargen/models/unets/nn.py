@@ -36,7 +36,7 @@ def gn32_coeffs(norm: "GroupNorm32", x, scale=None, shift=None):
     if x.dim() == 3:
         B, C, L = x.shape
         x = x.reshape(B, C, 1, L)
-    return K.groupnorm_coeffs(x, norm.num_groups, norm.eps, norm.weight, norm.bias, scale, shift)
+    return K.groupnorm_stats(x, norm.num_groups, norm.eps, norm.weight, norm.bias, scale, shift)
 
 
 class PointwiseConv1d(nn.Conv1d):

@@ -98,8 +98,9 @@ class GroupNorm(nn.GroupNorm):
                            act_silu=act_silu, out=out)
 
     def coeffs(self, x):
-        """Statistics only: per-(b, channel) rows the next conv applies while staging its input."""
-        return K.groupnorm_coeffs(x, self.num_groups, self.eps, self.weight, self.bias)
+        """Statistics only: the next conv derives the per-(b, channel) rows in its prologue and
+        applies them while staging its input."""
+        return K.groupnorm_stats(x, self.num_groups, self.eps, self.weight, self.bias)
 
 
 class AdaGN(nn.GroupNorm):
@@ -120,7 +121,7 @@ class AdaGN(nn.GroupNorm):
 
     def coeffs(self, x, emb=None, scale_shift=None):
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
-        return K.groupnorm_coeffs(x, self.num_groups, self.eps, None, None, scale, shift)
+        return K.groupnorm_stats(x, self.num_groups, self.eps, None, None, scale, shift)
 
 
 class ConditionalSequential(nn.Sequential):

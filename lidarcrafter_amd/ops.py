@@ -183,6 +183,11 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks):
         if prec == "f16x2":
             cpad = 0
+            gs_ref = None
+            if isinstance(gn_coeffs, GnStats):
+                if gn_coeffs.shape != (B, Ci, H, W):
+                    raise ValueError("conv: GroupNorm statistics belong to a different tensor")
+                gs_ref, gn_coeffs = gn_coeffs.byref(), None
             if gn_coeffs is not None:
                 _req(gn_coeffs, "gn_coeffs")
                 if gn_coeffs.dim() != 3 or gn_coeffs.shape[0] != B or gn_coeffs.shape[2] != 4 or \
@@ -193,7 +198,7 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                                                  _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                  Ci, Co, H, W, ks, float(out_scale),
                                                  int(tile_cfg), _p(gn_coeffs), cpad, int(gn_silu),
-                                                 _stream()),
+                                                 gs_ref, _stream()),
                   "lc_conv2d_ring_f16x2_fwd")
         else:
             check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res),
@@ -244,6 +249,52 @@ def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=
                                        _p(scale), _p(shift), ss_bs, out.data_ptr(), y_bs, B, C, H,
                                        W, G, float(eps), int(act_silu), st), "lc_groupnorm_apply")
     return out
+
+
+class GnStats:
+    """Statistics of ONE tensor + the GroupNorm / AdaGN parameters, for a conv that normalises its
+    input on the fly (`conv2d_ring(..., gn_coeffs=<GnStats>)`): the conv blocks derive the
+    per-channel rows themselves, no lc_groupnorm_coeffs launch.  Keeps everything it points to alive."""
+
+    __slots__ = ("shape", "_struct", "_keep")
+
+    def __init__(self, shape, part, G, nch, eps, gamma, beta, scale, shift, ss_bs):
+        from ._lib import GnStatsInput
+
+        self.shape = shape
+        self._keep = (part, gamma, beta, scale, shift)
+        self._struct = GnStatsInput(part.data_ptr(), G, nch, float(eps), _p(gamma), _p(beta),
+                                    _p(scale), _p(shift), ss_bs)
+
+    def byref(self):
+        import ctypes as C
+
+        return C.byref(self._struct)
+
+
+def groupnorm_stats(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=None,
+                    shift=None) -> GnStats:
+    """Statistics pass only (one launch); the consumer conv turns them into rows in its prologue."""
+    x_bs = _bs4(x, "x")
+    B, C, H, W = x.shape
+    if C % G:
+        raise ValueError(f"groupnorm: C={C} not divisible by G={G}")
+    ss_bs = 0
+    if scale is not None:
+        _req(scale, "scale"), _req(shift, "shift")
+        if scale.shape != (B, C) or shift.shape != (B, C) or scale.stride(1) != 1 or \
+                shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+            raise ValueError("groupnorm: scale/shift must be [B,C] with unit inner stride")
+        ss_bs = scale.stride(0)
+    for n_, t_ in (("gamma", gamma), ("beta", beta)):
+        if t_ is not None:
+            _req(t_, n_)
+    n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
+    part = torch.empty((n,), device=x.device, dtype=torch.float64)   # owned by the handle
+    with _Timed("groupnorm", 4.0 * B * C * H * W):
+        check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, _stream()),
+              "lc_groupnorm_stats")
+    return GnStats((B, C, H, W), part, G, n // (2 * B * G), eps, gamma, beta, scale, shift, ss_bs)
 
 
 def groupnorm_coeffs(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=None,

@@ -93,6 +93,19 @@ def test_conv_fused_groupnorm(dev, B, Ci, Co, H, W, ks, G, cfg):
     y2 = K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev), bias.to(dev), tile_cfg=cfg,
                        precision="f16x2", gn_coeffs=co2, gn_silu=False)
     assert rel_l2(y2, ref2) < 3e-6, rel_l2(y2, ref2)
+    # statistics handed to the conv directly (rows derived in its prologue): identical bits
+    xd = x.to(dev)
+    st = K.groupnorm_stats(xd, G, 1e-6, ga.to(dev), be.to(dev), ssd[:, :Ci], ssd[:, Ci:])
+    y3 = K.conv2d_ring(xd, K.PackedConv(), w.to(dev), bias.to(dev), tile_cfg=cfg, precision="f16x2",
+                       gn_coeffs=st, gn_silu=True)
+    assert torch.equal(y3, y)
+    st2 = K.groupnorm_stats(xd, G, 1e-6, ga.to(dev), be.to(dev))
+    y4 = K.conv2d_ring(xd, K.PackedConv(), w.to(dev), bias.to(dev), tile_cfg=cfg, precision="f16x2",
+                       gn_coeffs=st2, gn_silu=False)
+    assert torch.equal(y4, y2)
+    other = K.groupnorm_stats(torch.zeros(B, Ci, H, 2 * W, device=dev), G, 1e-6)
+    with pytest.raises(ValueError):      # statistics of a different tensor shape are refused
+        K.conv2d_ring(xd, K.PackedConv(), w.to(dev), bias.to(dev), gn_coeffs=other)
 
 
 def test_conv_strided_views(dev):
