@@ -186,11 +186,31 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
 
     def _capture(self, st):
         """Record one step (denoiser forward + fused update) into a HIP graph that reads its
-        per-step parameters from static buffers."""
-        B, x = st["B"], st["x"]
-        g = dict(lam=torch.empty_like(st["lam"][0]), coef=torch.empty_like(st["coef"][0]),
-                 tf=None if st["tf"] is None else tuple(torch.empty_like(a[:B]) for a in st["tf"]),
+        per-step parameters (log-SNR, update coefficients, time features) from ONE static row; the
+        rows of all remaining steps are packed into a [S, P] table, so a replay is preceded by a
+        single device copy."""
+        B, x, S = st["B"], st["x"], st["n"]
+        parts = [st["lam"].reshape(S, -1), st["coef"].reshape(S, -1)]
+        shapes = [tuple(st["lam"].shape[1:]), tuple(st["coef"].shape[1:])]
+        if st["tf"] is not None:
+            for a in st["tf"]:
+                parts.append(a.reshape(S, -1))
+                shapes.append((B,) + tuple(a.shape[1:]))
+        pad = lambda n: (n + 3) // 4 * 4                       # keep every view 16-byte aligned
+        widths = [p.shape[1] for p in parts]
+        offs, P = [], 0
+        for w in widths:
+            offs.append(P)
+            P += pad(w)
+        table = torch.zeros((S, P), device=x.device, dtype=torch.float32)
+        for p, o, w in zip(parts, offs, widths):
+            table[:, o:o + w] = p
+        row = torch.empty((P,), device=x.device, dtype=torch.float32)
+        views = [row[o:o + w].view(shp) for o, w, shp in zip(offs, widths, shapes)]
+        g = dict(table=table, row=row, lam=views[0], coef=views[1],
+                 tf=None if st["tf"] is None else tuple(views[2:]),
                  noise=torch.empty_like(x).contiguous() if st["needs_noise"] else None)
+        row.copy_(table[st["i"]])
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._step_body(st, g["lam"], g["tf"], g["coef"], g["noise"])
@@ -218,11 +238,7 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
                 self._step_body(st, st["lam"][i], tf, st["coef"][i], noise)
                 st["i"] = i + 1
                 return x
-            g["lam"].copy_(st["lam"][i])
-            g["coef"].copy_(st["coef"][i])
-            if tf is not None:
-                for dst, src in zip(g["tf"], tf):
-                    dst.copy_(src)
+            g["row"].copy_(g["table"][i])
             if g["noise"] is not None:
                 g["noise"].copy_(noise)
             g["graph"].replay()
