@@ -709,6 +709,7 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 22: return launch_pipe<HCfg<1, 8, 2, 1, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px
         case 23: return launch_pipe<HCfg<2, 4, 1, 2, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px (1x2)
         case 25: return launch_pipe<HCfg<2, 4, 1, 1, 2, 64, KS>>(a, st);  // 8 waves, 64 co x 128 px
+        case 28: return launch_pipe<HCfg<1, 8, 1, 1, 4, 64, KS>>(a, st);  // 8 waves, 32 co x 256 px (Co <= 32)
         default: return LC_EUNSUP;
     }
 }
@@ -726,6 +727,7 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     if (ks == 1)    // one tap per chunk: nothing to pipeline, two resident blocks per CU win (1.3-2x)
         return (t128 && blocks(64, 128) >= 512) ? 5 : 3;
     if (Ci >= 64) {    // 8-wave pipelined blocks: 230-333 TF when >= 1 block per CU exists
+        if (Co <= 32 && t256 && blocks(64, 256) >= 256) return 28;   // output head (Co = 2)
         if (t256 && blocks(64, 256) >= 256) return 23;
         if (t128 && blocks(64, 128) >= 256) return 25;
         return 13;
