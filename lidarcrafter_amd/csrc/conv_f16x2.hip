@@ -726,7 +726,8 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     const bool t256 = H % 4 == 0 && W % 64 == 0, t128 = H % 2 == 0 && W % 64 == 0;
     if (ks == 1)    // one tap per chunk: nothing to pipeline, two resident blocks per CU win (1.3-2x)
         return (t128 && blocks(64, 128) >= 512) ? 5 : 3;
-    if (Ci >= 64) {    // 8-wave pipelined blocks: 230-333 TF when >= 1 block per CU exists
+    if (Ci >= 24) {    // 8-wave pipelined, persistent blocks: 230-333 TF when >= 1 block per CU
+                       // exists (also the 32-channel input layer: 41 vs 70 us on the other kernel)
         if (Co <= 32 && t256 && blocks(64, 256) >= 256) return 28;   // output head (Co = 2)
         if (t256 && blocks(64, 256) >= 256) return 23;
         if (t128 && blocks(64, 128) >= 256) return 25;
