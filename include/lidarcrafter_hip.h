@@ -306,6 +306,11 @@ int lc_bev_histogram(const float* pts, int pt_stride, int N, const float* edges,
 int64_t lc_rbf_partials_elems(int M, int Mq);
 int lc_rbf_kernel_sum(const float* p, const float* q, int M, int Mq, int D, float gamma,
                       double* partials, lc_stream_t s);
+/* Chamfer distance forward (lidargen/metrics/modules/chamfer3D/chamfer3D.cu:12-155 via
+ * dist_chamfer_3D.py:27-49): xyz1 [B,N,3], xyz2 [B,M,3] -> squared distance to and index of the
+ * nearest point of the other set, both directions; first minimum wins. */
+int lc_chamfer3d_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float* dist1,
+                     int32_t* idx1, float* dist2, int32_t* idx2, lc_stream_t s);
 
 #ifdef __cplusplus
 }

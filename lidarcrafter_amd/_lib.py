@@ -69,6 +69,7 @@ SIGNATURES = {
     "lc_bev_histogram": (i32, [vp, i32, i32, vp, i32, f32, f32, vp, vp, vp]),
     "lc_rbf_partials_elems": (i64, [i32, i32]),
     "lc_rbf_kernel_sum": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
+    "lc_chamfer3d_fwd": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "lc_compact_scratch_elems": (i64, [i32]),
     "lc_compact_points": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "lc_points_in_boxes_index": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),

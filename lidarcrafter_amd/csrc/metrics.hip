@@ -115,3 +115,54 @@ extern "C" int lc_rbf_kernel_sum(const float* p, const float* q, int M, int Mq, 
     hipLaunchKernelGGL(rbf_sum_kernel, grid, dim3(256), 0, lc_s(s), p, q, M, Mq, D, gamma, partials);
     return lc_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Chamfer distance, forward: lidargen/metrics/modules/chamfer3D/chamfer3D.cu:12-120
+// (NmDistanceKernel, launched once per direction): for every point of xyz1 the squared distance to
+// and the index of its nearest point of xyz2 (first minimum wins).  One thread per query point,
+// targets streamed through LDS in tiles of 512; d = (dx*dx + dy*dy) + dz*dz with separate
+// roundings (no contraction) so that a float32 CPU restatement reproduces it bit for bit.
+namespace {
+
+#pragma clang fp contract(off)
+
+constexpr int NN_TILE = 512;
+
+__global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ q, int n,
+                                                const float* __restrict__ t, int m,
+                                                float* __restrict__ dist, int* __restrict__ idx) {
+    __shared__ float buf[NN_TILE * 3];
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const float* qb = q + (long long)b * n * 3;
+    const float* tb = t + (long long)b * m * 3;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (j < n) { x1 = qb[3 * j]; y1 = qb[3 * j + 1]; z1 = qb[3 * j + 2]; }
+    float best = 0.f;
+    int best_i = 0;
+    for (int k2 = 0; k2 < m; k2 += NN_TILE) {
+        const int cnt = (m - k2 < NN_TILE ? m - k2 : NN_TILE);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 3; e += 256) buf[e] = tb[(long long)k2 * 3 + e];
+        __syncthreads();
+        for (int k = 0; k < cnt; ++k) {
+            const float dx = buf[3 * k] - x1, dy = buf[3 * k + 1] - y1, dz = buf[3 * k + 2] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            if ((k2 == 0 && k == 0) || d < best) { best = d; best_i = k2 + k; }
+        }
+    }
+    if (j < n) { dist[(long long)b * n + j] = best; idx[(long long)b * n + j] = best_i; }
+}
+
+}  // namespace
+
+extern "C" int lc_chamfer3d_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float* dist1,
+                                int32_t* idx1, float* dist2, int32_t* idx2, lc_stream_t s) {
+    if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || B <= 0 || N <= 0 || M <= 0)
+        return LC_EINVAL;
+    hipLaunchKernelGGL(nn_kernel, dim3((N + 255) / 256, B), dim3(256), 0, lc_s(s), xyz1, N, xyz2, M,
+                       dist1, idx1);
+    hipLaunchKernelGGL(nn_kernel, dim3((M + 255) / 256, B), dim3(256), 0, lc_s(s), xyz2, M, xyz1, N,
+                       dist2, idx2);
+    return lc_launch_status();
+}

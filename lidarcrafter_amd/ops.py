@@ -626,6 +626,27 @@ def rbf_kernel_mean(p: torch.Tensor, q: torch.Tensor, sigma: float = 0.5) -> tor
     return part.sum() / (M * Mq)
 
 
+def chamfer3d(xyz1: torch.Tensor, xyz2: torch.Tensor):
+    """xyz1 [B,N,3], xyz2 [B,M,3] -> (dist1 [B,N], dist2 [B,M], idx1 int32 [B,N], idx2 int32 [B,M]):
+    squared nearest-neighbour distances both ways (dist_chamfer_3D.py:27-49)."""
+    _req(xyz1, "xyz1"), _req(xyz2, "xyz2")
+    if xyz1.dim() != 3 or xyz2.dim() != 3 or xyz1.shape[2] != 3 or xyz2.shape[2] != 3 or \
+            xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("chamfer3d: expected [B,N,3] and [B,M,3]")
+    xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    dev = xyz1.device
+    d1 = torch.empty((B, N), device=dev, dtype=_F32)
+    d2 = torch.empty((B, M), device=dev, dtype=_F32)
+    i1 = torch.empty((B, N), device=dev, dtype=torch.int32)
+    i2 = torch.empty((B, M), device=dev, dtype=torch.int32)
+    check(lib().lc_chamfer3d_fwd(xyz1.data_ptr(), xyz2.data_ptr(), B, N, M, d1.data_ptr(),
+                                 i1.data_ptr(), d2.data_ptr(), i2.data_ptr(), _stream()),
+          "lc_chamfer3d_fwd")
+    return d1, d2, i1, i2
+
+
 def roiaware_pool3d_forward(rois, pts, pts_feature, out_size, max_pts_each_voxel: int, method: int):
     """-> (pooled [N,X,Y,Z,C], pts_idx_of_voxels int32 [N,X,Y,Z,max_pts], argmax int32 [N,X,Y,Z,C])."""
     for n_, t_ in (("rois", rois), ("pts", pts), ("pts_feature", pts_feature)):

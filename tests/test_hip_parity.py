@@ -952,3 +952,26 @@ def test_discrete_time_sampler_golden(dev, golden):
             assert torch.equal(xs[0], ref[0])
             for i in range(1, 4):
                 assert rel_l2(xs[i], ref[i]) < 1e-3, (kind, mode, i, rel_l2(xs[i], ref[i]))
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 1000, 777), (1, 1, 5), (1, 512, 1024), (3, 300, 513)])
+def test_chamfer3d_bit_exact(dev, B, N, M):
+    """lc_chamfer3d_fwd vs the float32 numpy restatement: distances and indices identical,
+    duplicates resolved to the first minimum; compute_pairwise_cd(_batch) on top of it."""
+    import lidargen  # noqa: F401
+    from lidargen.metrics import chamfer
+    from oracle import metrics as OM
+
+    g = np.random.default_rng(B * 1000 + N)
+    a = g.normal(0, 20, (B, N, 3)).astype(np.float32)
+    b = g.normal(0, 20, (B, M, 3)).astype(np.float32)
+    if M > 4:
+        b[:, 3] = b[:, 1]                                   # a duplicated target: index 1 must win
+    d1, d2, i1, i2 = chamfer.chamfer_3DDist()(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+    r1, r2, j1, j2 = OM.chamfer3d(a, b)
+    assert np.array_equal(d1.cpu().numpy(), r1) and np.array_equal(i1.cpu().numpy(), j1)
+    assert np.array_equal(d2.cpu().numpy(), r2) and np.array_equal(i2.cpu().numpy(), j2)
+    cd = chamfer.compute_pairwise_cd(a[0], b[0])
+    assert abs(cd - float((r1[0].mean() + r2[0].mean()) / 2)) < 1e-4 * max(1.0, cd)
+    res = chamfer.compute_pairwise_cd_batch(a[0], [b[0], b[0][: max(1, M // 2)]])
+    assert abs(res[0] - cd) < 1e-4 * max(1.0, cd) and len(res) == 2
