@@ -126,6 +126,46 @@ def sequence(dev, B, frames, steps):
                     "CustomDataset item + collate, RNG draws on the host for DDPM noise"}
 
 
+def pipeline_metrics(dev, B, n_batches, steps):
+    """C5-shaped flow on one GPU: sample two sets of frames (different seeds), post-process to
+    points, BEV histograms, JSD / MMD between the sets and the chamfer distance of one pair --
+    everything on the device (random-init weights: the VALUES are meaningless, the flow is real)."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.metrics import bev, chamfer
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model, lu = inference.load_model_duffusion_training(C["nuscenes-unet-uncond"]())
+    seeded_fill(model, salt=100)
+    ddpm, lu = ddpm.eval().to(dev), lu.to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sets, clouds = [], []
+    for s in range(2):
+        hs = []
+        for k in range(n_batches):
+            rng = [torch.Generator().manual_seed(1000 * s + k * B + i) for i in range(B)]
+            fr = lu.postprocess(ddpm.sample(B, steps, progress=False, rng=rng, mode="ddim").clamp(-1, 1))
+            for b in range(B):
+                pts, keep = K.image_to_points(fr[b, 1:4].contiguous(), fr[b, 4].contiguous(), None, 1.0,
+                                              min_norm=1e-2)
+                pts = K.compact_points(pts, keep)
+                hs.append(bev.point_cloud_to_histogram(pts))
+                if b == 0 and k == 0:
+                    clouds.append(pts[:, :3].contiguous())
+        sets.append(torch.stack(hs))
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    jsd, mmd = bev.compute_jsd_2d(sets[0], sets[1]), bev.compute_mmd_2d(sets[0], sets[1])
+    cd = chamfer.compute_pairwise_cd(clouds[0], clouds[1])
+    torch.cuda.synchronize()
+    return {"frames_per_set": B * n_batches, "ddim_steps": steps, "generate_and_histogram_s": round(t_gen, 3),
+            "metrics_s": round(time.perf_counter() - t0, 4), "bev_jsd": float(jsd), "bev_mmd": float(mmd),
+            "chamfer": float(cd)}
+
+
 def projection(dev, N):
     from lidarcrafter_amd import ops as K
     from lidarcrafter_amd.testing import synth_points
@@ -164,6 +204,7 @@ def main():
     if not args.quick:
         out["uncond_64x2048"] = [uncond(dev, 4, (64, 2048), 6, "uncond64")]
     out["temporal_sequence_32x1024"] = [sequence(dev, 2, 5, 16 if args.quick else 32)]
+    out["pipeline_metrics_c5_shape"] = [pipeline_metrics(dev, 8, 1 if args.quick else 2, 8)]
     out["projection"] = [projection(dev, N) for N in (34720, 131072, 1 << 22)]
     out["points_in_boxes_mask"] = [pib(dev, N, nb) for N, nb in ((34720, 13), (1 << 22, 13))]
     print(json.dumps(out, indent=1))
