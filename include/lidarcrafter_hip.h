@@ -84,7 +84,17 @@ int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, co
                              float out_scale, int tile_cfg /* 0 = auto */,
                              const float* gn_coeffs /* NULL or [B, gn_cpad, 4] */, int gn_cpad,
                              int gn_silu, const lc_gn_stats_input* gn_stats /* NULL, or instead of
-                             gn_coeffs */, lc_stream_t s);
+                             gn_coeffs */,
+                             float* gn_ostats_out /* NULL or [B, Co/8, slots, 4], see below */,
+                             lc_stream_t s);
+/* Output statistics for the NEXT GroupNorm (every GroupNorm input of the denoiser is a conv
+ * output, efficient_unet.py:101-108): with gn_ostats_out != NULL every wave of the pipelined kernel
+ * also writes, per octet of 8 consecutive output channels and wave tile, the entry
+ * (pivot, n, sum(y - pivot), sum((y - pivot)^2)) of the values it stored; lc_groupnorm_apply_os
+ * folds them, so no statistics pass re-reads the tensor.  slots = entries per (sample, octet) for
+ * this problem and tile configuration, 0 when the chosen kernel emits none (Co % 8 != 0, or the
+ * 2-blocks/CU kernel): ask before allocating. */
+int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, int ks, int tile_cfg);
 /* Fused input normalisation: with gn_coeffs != NULL the kernel applies
  *   x <- silu?( (x - mu) * A + Bc )       rows (mu, A, Bc, 0) from lc_groupnorm_coeffs
  * while staging the input tile (the GN -> SiLU -> Conv chain of efficient_unet.py:101-108 and
@@ -113,6 +123,21 @@ int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials, con
                        const float* beta, const float* scale, const float* shift, int64_t ss_bs,
                        float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
                        int act_silu, lc_stream_t s);
+
+/* The same normalisation from the PRODUCER's octet statistics (lc_conv2d_ring_f16x2_fwd
+ * gn_ostats_out): one launch, the tensor is read once.  A tensor may be the channel concatenation of
+ * two producers' outputs (torch.cat([h, skip]) efficient_unet.py:293-295): s0 covers channels
+ * [0, s0->channels), s1 (may be NULL) the rest.  Needs (C/G) % 8 == 0 and every group inside one
+ * segment (LC_EUNSUP otherwise: use stats + apply).  The fold is fp64 around one common pivot per
+ * group in a fixed order (deterministic). */
+typedef struct lc_oct_stats {
+    const float* p;     /* [B, channels/8, slots, 4] */
+    int channels, slots;
+} lc_oct_stats;
+int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_stats* s0, const lc_oct_stats* s1,
+                          const float* gamma, const float* beta, const float* scale,
+                          const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B, int C,
+                          int H, int W, int G, float eps, int act_silu, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * FIR resampling x2, window [1,3,3,1], ring=True: ops.Resample ops.py:52-146

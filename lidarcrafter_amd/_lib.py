@@ -26,6 +26,14 @@ class GnStatsInput(C.Structure):
 
 _gs = C.POINTER(GnStatsInput)
 
+
+class OctStats(C.Structure):
+    """struct lc_oct_stats: producer-side GroupNorm statistics of one channel segment."""
+    _fields_ = [("p", vp), ("channels", i32), ("slots", i32)]
+
+
+_os = C.POINTER(OctStats)
+
 # name -> (restype, argtypes); mirrors include/lidarcrafter_hip.h one to one
 SIGNATURES = {
     "lc_abi_version": (i32, []),
@@ -37,13 +45,16 @@ SIGNATURES = {
     "lc_packed_conv_weight_f16x2_elems": (i64, [i32, i32, i32]),
     "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "lc_conv2d_ring_f16x2_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
-                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp]),
+                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp, vp]),
+    "lc_conv2d_ring_f16x2_stats_slots": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "lc_groupnorm_coeffs": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, f32, vp]),
     "lc_groupnorm_partials_elems": (i64, [i32, i32, i32, i32, i32]),
     "lc_groupnorm_stats": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
     "lc_groupnorm_apply": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
                                  i32, f32, i32, vp]),
+    "lc_groupnorm_apply_os": (i32, [vp, i64, _os, _os, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32,
+                                    i32, i32, f32, i32, vp]),
     "lc_resample2x_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
     "lc_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "lc_sinusoid_fwd": (i32, [vp, vp, i32, i32, f32, vp]),

@@ -21,10 +21,21 @@
 
 namespace {
 
+// Output store of the conv epilogues.  Mode 2 marks the store write-through (sc1): the lines do
+// not stay dirty in L2, so the kernel-end release has less to flush.
+__device__ __forceinline__ void epi_store(float* p, float v) {
+#if LC_EPI_MODE == 2
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #ifndef LC_EPI_MODE
-#define LC_EPI_MODE 2   // 0 flat predicated stores, 1 raw buffer stores, 2 buffer stores sc1 (write-through)
+#define LC_EPI_MODE 2   // 0 plain stores, 2 write-through (sc1) stores (developer A/B)
 #endif
 #ifndef LC_ABLATE
 #define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
@@ -52,6 +63,12 @@ struct ConvArgsH {
     int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles of one sample
     int vert;  // 1: the block walks its tpb tiles down H (W-neighbours run concurrently), 0: along W
     int xcd;   // 1: blockIdx.x is remapped so that each XCD owns a contiguous range of tiles
+    // optional GroupNorm statistics of the OUTPUT for the next GroupNorm (lc_groupnorm_apply_os):
+    // per sample, channel octet (8 consecutive channels) and wave tile one entry
+    // (pivot, n, sum(y - pivot), sum((y - pivot)^2));  ostats[(b*Co/8 + octet)*oslots + slot],
+    // slot = (tile_row*tiles_w + tile_col)*WPX + wave_px.  Pipelined kernel only.
+    f32x4* ostats;
+    int oslots;
 };
 
 constexpr int GN_MAX_C = 1024;   // LDS table of fused GroupNorm rows: 16 KB
@@ -328,7 +345,24 @@ __device__ __forceinline__ void split_store(const float (&v)[8], half8* dst_hi, 
     *dst_lo = lo;
 }
 
-template <class C>
+// 64-lane sum with DPP adds (VALU rate, no LDS): row_shr 1,2,4,8, then row_bcast:15 into rows 1,3
+// and row_bcast:31 into rows 2,3 -- lane 63 ends up with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v),
+                                                                     CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);
+    v = dpp_add<0x143, 0xC>(v);
+    return v;
+}
+
+template <class C, bool EMIT_STATS>
 __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(ConvArgsH a) {
     constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
     constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
@@ -605,8 +639,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         half8* t = cur; cur = nxt; nxt = t;
     };
     float* yb = a.y + (long long)b * a.y_bs;
-    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)yb, 0, (unsigned)a.Co * (unsigned)HW * 4u, 0x00020000);
     for (int tile = 0; tile < tpb; ++tile) {
         for (int ch = 0; ch < last; ++ch) k_iter(ch, ch + 1);
         prefetch_res();          // the last chunk is peeled: no branch in the steady-state loop
@@ -614,41 +646,67 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         if (more) set_tile(h0 + dh, w0 + dw);         // x offsets of the NEXT tile (uniform branch)
         k_iter(last, more ? 0 : last);                // prefetches chunk 0 of the next tile
         // ---- epilogue of this tile: stores only (bias / residual already in registers) --------
-        // Raw buffer stores: channels >= Co fall outside the descriptor and are dropped, pixels
-        // outside the plane get an out-of-range offset.  LC_EPI_MODE 2: agent-scope write-through
-        // (sc1) -- the tile goes to memory while the block keeps computing instead of sitting dirty
-        // in this XCD's L2 until the end-of-kernel write-back (MI355X_MICROARCH.md "boundary":
-        // + dirty bytes / 6 TB/s per dependent launch); measured +0.7 % steps/s over mode 1.
-        auto store_tile = [&](auto mode) {
-            constexpr int MODE = decltype(mode)::value;
+        // (EMIT_STATS is a kernel template parameter, not a branch: the statistics code must not
+        //  cost the plain kernel any registers)
+        // statistics of what is stored, one accumulator pair per octet (8 channels = registers
+        // 4m..4m+3 of both lane halves), around the tile's first value of that octet
+        float st_p[C::TCO_][4], st_s[C::TCO_][4], st_q[C::TCO_][4];
+        int nvalid = 0;
 #pragma unroll
-            for (int j = 0; j < C::TPX_; ++j) {
-                const int t = wpx * C::TPX_ + j;
-                const int tr = t / C::TPR, tc = t - tr * C::TPR;
-                const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-                const bool pok = gh < H && gw < W;
-                const long long poff = (long long)gh * W + gw;
+        for (int j = 0; j < C::TPX_; ++j) {
+            const int t = wpx * C::TPX_ + j;
+            const int tr = t / C::TPR, tc = t - tr * C::TPR;
+            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+            const bool pok = gh < H && gw < W;
+            const long long poff = (long long)gh * W + gw;
+            if constexpr (EMIT_STATS) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
 #pragma unroll
-                for (int i = 0; i < C::TCO_; ++i) {
+            for (int i = 0; i < C::TCO_; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if constexpr (!EMIT_STATS) {
+                        if (pok && co < a.Co) {
+                            const float v = (acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r];
+                            epi_store(&yb[(long long)co * HW + poff], v * a.out_scale);
+                        }
+                    } else {
                         const float v = ((acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r]) *
                                         a.out_scale;
-                        if constexpr (MODE == 0) {
-                            if (pok && co < a.Co) yb[(long long)co * HW + poff] = v;
-                        } else {
-                            const unsigned off = pok ? ((unsigned)co * (unsigned)HW + (unsigned)poff) * 4u
-                                                     : 0xFFFFFFF0u;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), yrs, off, 0,
-                                                                  MODE == 2 ? 16 : 0);
+                        if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
+                        const int m = r >> 2;
+                        if (j == 0 && (r & 3) == 0) {
+                            st_p[i][m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
+                            st_s[i][m] = 0.f; st_q[i][m] = 0.f;
                         }
-                        acc[i][j][r] = 0.0f;
+                        const float d = pok ? v - st_p[i][m] : 0.0f;
+                        st_s[i][m] += d;
+                        st_q[i][m] = fmaf(d, d, st_q[i][m]);
                     }
+                    acc[i][j][r] = 0.0f;
                 }
             }
-        };
-        store_tile(std::integral_constant<int, LC_EPI_MODE>{});
+        }
+        if constexpr (EMIT_STATS) {
+            // launder the loop-invariant inputs of the entry addresses / store predicates: hipcc
+            // would otherwise hoist them above the K loop and spill them across it
+            int oslots = a.oslots, co_lim = a.Co;
+            asm volatile("" : "+s"(oslots), "+s"(co_lim));
+            const int slot = ((h0 / C::TH_) * a.tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
+            const int co_blk = co0 + wco * C::TCO_ * 32;       // first channel of this wave's rows
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int co_oct = co_blk + i * 32 + 8 * m;
+                    const float s_ = wave_sum_to_lane63(st_s[i][m]);
+                    const float q_ = wave_sum_to_lane63(st_q[i][m]);
+                    if (lane == 63 && co_oct < co_lim)
+                        a.ostats[((long long)b * (co_lim >> 3) + (co_oct >> 3)) * oslots + slot] =
+                            f32x4{st_p[i][m], (float)(8 * nvalid), s_, q_};
+                }
+            }
+        }
         h0 += dh; w0 += dw;
     }
 }
@@ -682,7 +740,8 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     dim3 grid(a.B * a.tiles_h * a.tiles_w / tpb, ncot);
     a.xcd = (xcd_env && grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
 
-    hipLaunchKernelGGL(conv_f16x2_pipe_kernel<C>, grid, dim3(C::NT), 0, st, a);
+    if (a.ostats) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
     return lc_launch_status();
 }
 
@@ -712,6 +771,23 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 28: return launch_pipe<HCfg<1, 8, 1, 1, 4, 64, KS>>(a, st);  // 8 waves, 32 co x 256 px (Co <= 32)
         default: return LC_EUNSUP;
     }
+}
+
+// wave tiles per (sample, channel) plane of the pipelined configurations = statistics entries per
+// channel octet; 0 for the configurations of the other kernel (they emit no statistics)
+int pipe_stat_slots(int cfg, int H, int W) {
+    int th, tw, wpx;
+    switch (cfg) {
+        case 12: th = 4; tw = 64; wpx = 4; break;
+        case 13: th = 2; tw = 32; wpx = 2; break;
+        case 15: th = 2; tw = 64; wpx = 4; break;
+        case 22: th = 4; tw = 64; wpx = 8; break;
+        case 23: th = 4; tw = 64; wpx = 4; break;
+        case 25: th = 2; tw = 64; wpx = 4; break;
+        case 28: th = 4; tw = 64; wpx = 8; break;
+        default: return 0;
+    }
+    return ((H + th - 1) / th) * ((W + tw - 1) / tw) * wpx;
 }
 
 int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
@@ -781,7 +857,8 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
                                         int64_t res_bs, float* y, int64_t y_bs, int B, int Ci,
                                         int Co, int H, int W, int ks, float out_scale, int tile_cfg,
                                         const float* gn_coeffs, int gn_cpad, int gn_silu,
-                                        const lc_gn_stats_input* gn_stats, lc_stream_t s) {
+                                        const lc_gn_stats_input* gn_stats, float* gn_ostats_out,
+                                        lc_stream_t s) {
     if (!x || !wp_hi || !wp_lo || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0)
         return LC_EINVAL;
     if (ks != 1 && ks != 3) return LC_EUNSUP;
@@ -815,5 +892,20 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
         a.W = W = 64;
     }
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
+    a.ostats = nullptr; a.oslots = 0;
+    if (gn_ostats_out) {
+        a.oslots = pipe_stat_slots(tile_cfg, H, W);
+        if (a.oslots <= 0 || Co % 8) return LC_EUNSUP;     // ask lc_conv2d_ring_f16x2_stats_slots first
+        a.ostats = reinterpret_cast<f32x4*>(gn_ostats_out);
+    }
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
+}
+
+extern "C" int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, int ks,
+                                                    int tile_cfg) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Co % 8 || H <= 0 || W <= 0 || (ks != 1 && ks != 3)) return 0;
+    if (tile_cfg >= 100) tile_cfg %= 100;
+    if (ks == 1 && ((long long)H * W) % 128 == 0) { H = (int)(((long long)H * W) / 64); W = 64; }
+    if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
+    return pipe_stat_slots(tile_cfg, H, W);
 }

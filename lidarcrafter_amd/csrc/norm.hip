@@ -133,6 +133,87 @@ __global__ void gn_coeffs_kernel(const double* __restrict__ part, const float* _
     out[i] = r;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm apply fed by the PRODUCER's statistics (conv epilogue, conv_f16x2.hip): entries
+// (pivot, n, S = sum(y - pivot), Q = sum((y - pivot)^2)) per (sample, octet of 8 channels, wave
+// tile); a group's entries are contiguous.  Every entry is re-centred on ONE common pivot P0 (the
+// group's first entry's pivot, a typical value of the tensor):
+//   S' = S + n d,  Q' = Q + d (2 S + n d),  d = pivot - P0
+// and fp64 sums of N, S', Q' give mean = P0 + S'/N, var = Q'/N - (S'/N)^2: no division per entry,
+// no cancellation beyond |mean - P0| / std (a few), fixed summation order (deterministic).
+struct OctStats2 {
+    const f32x4* p0; const f32x4* p1;     // segment 0: channels [0, c0), segment 1: [c0, c0 + c1)
+    int c0, slots0, c1, slots1;
+};
+
+__global__ __launch_bounds__(256) void gn_apply_os_kernel(
+    const float* __restrict__ x, long long x_bs, OctStats2 os, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift,
+    long long ss_bs, float* __restrict__ y, long long y_bs, int C, int G, long long HW, float eps,
+    int act, int cpb) {
+    __shared__ double sh[12];
+    const int c_first = blockIdx.y * cpb, b = blockIdx.z;
+    const int cpg = C / G, g = c_first / cpg;
+    const int cg0 = g * cpg;                                   // first channel of the group
+    const bool seg1 = cg0 >= os.c0;
+    const int slots = seg1 ? os.slots1 : os.slots0;
+    const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> 3) + ((cg0 - os.c0) >> 3)) * slots
+                          : os.p0 + ((long long)b * (os.c0 >> 3) + (cg0 >> 3)) * slots;
+    const int n_ent = (cpg >> 3) * slots;
+    const double P0 = (double)e[0].x;
+    double N = 0.0, S = 0.0, Q = 0.0;
+    for (int i = threadIdx.x; i < n_ent; i += 256) {
+        const f32x4 v = e[i];
+        const double n = v.y, d = (double)v.x - P0, s_ = v.z;
+        N += n;
+        S += s_ + n * d;
+        Q += (double)v.w + d * (2.0 * s_ + n * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        N += __shfl_xor(N, o, 64); S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[3 * wv] = N; sh[3 * wv + 1] = S; sh[3 * wv + 2] = Q; }
+    __syncthreads();
+    N = (sh[0] + sh[3]) + (sh[6] + sh[9]);
+    S = (sh[1] + sh[4]) + (sh[7] + sh[10]);
+    Q = (sh[2] + sh[5]) + (sh[8] + sh[11]);
+    const double m = N > 0.0 ? S / N : 0.0;
+    double var = N > 0.0 ? Q / N - m * m : 0.0;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)(P0 + m);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const long long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per;
+    const long long hi = lo + per < HW ? lo + per : HW;
+    for (int c = c_first; c < c_first + cpb; ++c) {
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+        const float sf = shift ? shift[b * ss_bs + c] : 0.0f;
+        const float* xp = x + b * x_bs + (long long)c * HW;
+        float* yp = y + b * y_bs + (long long)c * HW;
+        auto f = [&](float v) {
+            float t = (v - mu) * rstd;
+            t = t * ga + be;
+            t = t * sc + sf;
+            return act ? lc_silu(t) : t;
+        };
+        const bool vec = (HW & 3) == 0 && (per & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0;
+        if (vec) {
+            for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
+                v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+                *reinterpret_cast<f32x4*>(yp + i) = v;
+            }
+        } else {
+            for (long long i = lo + threadIdx.x; i < hi; i += 256) yp[i] = f(xp[i]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int lc_groupnorm_coeffs(const float* x, int64_t x_bs, const double* partials,
@@ -184,5 +265,36 @@ extern "C" int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* pa
     hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
                        (long long)x_bs, partials, gamma, beta, scale, shift, (long long)ss_bs, y,
                        (long long)y_bs, C, G, HW, nch, eps, act_silu, cpb);
+    return lc_launch_status();
+}
+
+
+extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_stats* s0,
+                                     const lc_oct_stats* s1, const float* gamma, const float* beta,
+                                     const float* scale, const float* shift, int64_t ss_bs, float* y,
+                                     int64_t y_bs, int B, int C, int H, int W, int G, float eps,
+                                     int act_silu, lc_stream_t s) {
+    if (!x || !y || B <= 0 || G <= 0 || C % G || !s0 || !s0->p || s0->channels <= 0 || s0->slots <= 0)
+        return LC_EINVAL;
+    OctStats2 os;
+    os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
+    os.p1 = nullptr; os.c1 = 0; os.slots1 = 0;
+    if (s1) {
+        if (!s1->p || s1->channels <= 0 || s1->slots <= 0) return LC_EINVAL;
+        os.p1 = reinterpret_cast<const f32x4*>(s1->p); os.c1 = s1->channels; os.slots1 = s1->slots;
+    }
+    const int cpg = C / G;
+    // octet-granular statistics: groups are whole octets and lie inside one segment
+    if (os.c0 + os.c1 != C || cpg % 8 || os.c0 % cpg || os.c0 % 8 || os.c1 % 8) return LC_EUNSUP;
+    const long long HW = (long long)H * W;
+    int slabs = (int)((HW + 4095) / 4096);
+    if (slabs < 1) slabs = 1;
+    int cpb = 1;
+    while (cpb * 2 <= cpg && cpg % (cpb * 2) == 0 && HW * cpb * 2 <= 4096 &&
+           (long long)B * (C / (cpb * 2)) * slabs >= 512)
+        cpb *= 2;
+    hipLaunchKernelGGL(gn_apply_os_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
+                       (long long)x_bs, os, gamma, beta, scale, shift, (long long)ss_bs, y,
+                       (long long)y_bs, C, G, HW, eps, act_silu, cpb);
     return lc_launch_status();
 }

@@ -106,15 +106,17 @@ class ResidualBlock(nn.Module):
             else:
                 sk = self.skip(x)
             return self.conv2(h, res=sk, out=out, out_scale=self._scale_f, gn_coeffs=c2)
+        # unfused GroupNorms (wide layers): the producing convs leave the statistics, the
+        # GroupNorm is a single apply pass
         a = self.norm1(x, act_silu=True)
-        h = self.conv1(a)
+        h = self.conv1(a, emit_stats=True)
         if self.has_emb:
             a = self.norm2(h, emb, scale_shift=scale_shift, act_silu=True, out=a
                            if a.shape == h.shape else None)
         else:
             a = self.norm2(h, act_silu=True)
         sk = x if isinstance(self.skip, nn.Identity) else self.skip(x, out=h)
-        return self.conv2(a, res=sk, out=out, out_scale=self._scale_f)
+        return self.conv2(a, res=sk, out=out, out_scale=self._scale_f, emit_stats=True)
 
 
 class Block(nn.Module):
@@ -151,8 +153,9 @@ class Block(nn.Module):
             h = rb(h, temb, scale_shift=ss, out=out if last else None)
         if has_attn:
             h = self.self_attn_block(h, out=out if not has_up else None)
-        if has_up:
-            h = self.upsample[1](self.upsample[0](h), out=out)
+        if has_up:   # feeds the next block's first GroupNorm (through the concat buffer)
+            h = self.upsample[1](self.upsample[0](h), out=out,
+                                 emit_stats=not K.fuse_gn(self.upsample[1].out_channels))
         return h
 
 

@@ -63,9 +63,12 @@ class Conv2d(nn.Conv2d):
         self._packed = K.PackedConv()
 
     def forward(self, x, res=None, out=None, out_scale: float = 1.0, gn_coeffs=None,
-                gn_silu: bool = True):
+                gn_silu: bool = True, emit_stats: bool = False):
+        """emit_stats: also leave GroupNorm statistics of the output for a following (unfused)
+        GroupNorm, so that it needs no statistics pass (ops.conv2d_ring)."""
         return K.conv2d_ring(x, self._packed, self.weight, self.bias, res=res, out=out,
-                             out_scale=out_scale, gn_coeffs=gn_coeffs, gn_silu=gn_silu)
+                             out_scale=out_scale, gn_coeffs=gn_coeffs, gn_silu=gn_silu,
+                             emit_stats=emit_stats)
 
 
 class Resample(nn.Module):

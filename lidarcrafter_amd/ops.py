@@ -102,6 +102,91 @@ def set_conv_precision(mode: str) -> str:
     return old
 
 
+# ------------------------------------------------------------------------------------ GN stats
+# Producer-side GroupNorm statistics: the pipelined f16x2 conv can emit, per octet of output
+# channels and wave tile, the shifted sums of what it stores (lc_conv2d_ring_f16x2_fwd
+# gn_ostats_out); a following `groupnorm(...)` then needs no statistics pass over the tensor.  The
+# handle travels as an attribute of the OUTPUT TENSOR OBJECT (for a channel slice of a concat
+# buffer: of the base buffer, keyed by channel range), so a different tensor that later reuses the
+# same memory can never pick up stale statistics, and every wrapper that writes into an `out=`
+# tensor drops the statistics of what it overwrites.
+PRODUCER_GN_STATS = _os.environ.get("LC_GN_PRODUCER_STATS", "1") != "0"
+
+
+class _OctStatsHandle:
+    __slots__ = ("buf", "channels", "slots", "shape")
+
+    def __init__(self, buf, channels, slots, shape):
+        self.buf, self.channels, self.slots, self.shape = buf, channels, slots, shape
+
+
+def _stats_owner(t: torch.Tensor):
+    """(owner tensor object, first channel of `t` inside it), or (None, 0) when `t` is not a plain
+    channel slice of its base."""
+    base = t._base
+    if base is None:
+        return t, 0
+    if base.dim() != 4 or t.dim() != 4 or base.stride() != t.stride() or \
+            base.shape[0] != t.shape[0] or base.shape[2:] != t.shape[2:]:
+        return None, 0
+    off = t.storage_offset() - base.storage_offset()
+    if off < 0 or off % base.stride(1):
+        return None, 0
+    return base, off // base.stride(1)
+
+
+def _drop_stats(t: Optional[torch.Tensor]) -> None:
+    """`t` is about to be (over)written: forget the statistics of that channel range."""
+    if t is None:
+        return
+    own, c0 = _stats_owner(t)
+    d = getattr(t, "_lc_gnstats", None)
+    if d and own is not t:
+        d.clear()
+    d = getattr(own, "_lc_gnstats", None) if own is not None else None
+    if d:
+        C = t.shape[1] if t.dim() == 4 else 1 << 30
+        for k in [k for k in d if k[0] < c0 + C and c0 < k[0] + k[1]]:
+            del d[k]
+
+
+def _attach_stats(out: torch.Tensor, h: _OctStatsHandle) -> None:
+    own, c0 = _stats_owner(out)
+    if own is None:
+        return
+    d = getattr(own, "_lc_gnstats", None)
+    if d is None:
+        d = {}
+        own._lc_gnstats = d
+    d[(c0, out.shape[1])] = h
+
+
+def _find_stats(x: torch.Tensor, G: int):
+    """Handles covering all channels of x with at most two segments (each a whole number of
+    groups, groups whole octets), or None."""
+    if x.dim() != 4:
+        return None
+    own, c0 = _stats_owner(x)
+    if own is None:
+        return None
+    d = getattr(own, "_lc_gnstats", None)
+    if not d:
+        return None
+    C = x.shape[1]
+    if C % G or (C // G) % 8:
+        return None
+    shape = (x.shape[0], x.shape[2], x.shape[3])
+    h = d.get((c0, C))
+    if h is not None and h.shape == shape:
+        return (h,)
+    for (k0, kc), h0 in d.items():
+        if k0 == c0 and kc < C and kc % (C // G) == 0:
+            h1 = d.get((c0 + kc, C - kc))
+            if h1 is not None and h0.shape == shape and h1.shape == shape:
+                return (h0, h1)
+    return None
+
+
 class PackedConv:
     """Packed copies of an OIHW conv weight for the MFMA kernels (fp32 wp[tap][Ci^8][Co^64] and/or
     the f16x2 hi/lo planes), rebuilt when the parameter changes."""
@@ -151,7 +236,8 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, out_scale: float = 1.0,
                 tile_cfg: int = 0, precision: Optional[str] = None,
-                gn_coeffs: Optional[torch.Tensor] = None, gn_silu: bool = True) -> torch.Tensor:
+                gn_coeffs: Optional[torch.Tensor] = None, gn_silu: bool = True,
+                emit_stats: bool = False) -> torch.Tensor:
     """y = (conv_ring(x', W) + bias [+ res]) * out_scale with x' = x, or -- when `gn_coeffs`
     (from `groupnorm_coeffs`) is given -- x' = silu?(GroupNorm(x)) applied on the fly while the
     input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference."""
@@ -180,6 +266,7 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     if bias is not None:
         _req(bias, "bias")
     ks = packed.ks
+    _drop_stats(out)
     with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks):
         if prec == "f16x2":
             cpad = 0
@@ -194,12 +281,19 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                         not gn_coeffs.is_contiguous():
                     raise ValueError("gn_coeffs must be contiguous [B, Cpad, 4]")
                 cpad = gn_coeffs.shape[1]
+            sbuf, slots = None, 0
+            if emit_stats and PRODUCER_GN_STATS:
+                slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, Ci, Co, H, W, ks, int(tile_cfg)))
+                if slots > 0:
+                    sbuf = torch.empty((B, Co // 8, slots, 4), device=x.device, dtype=_F32)
             check(lib().lc_conv2d_ring_f16x2_fwd(x.data_ptr(), x_bs, wh.data_ptr(), wl.data_ptr(),
                                                  _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                  Ci, Co, H, W, ks, float(out_scale),
                                                  int(tile_cfg), _p(gn_coeffs), cpad, int(gn_silu),
-                                                 gs_ref, _stream()),
+                                                 gs_ref, _p(sbuf), _stream()),
                   "lc_conv2d_ring_f16x2_fwd")
+            if sbuf is not None:
+                _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H, W)))
         else:
             check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res),
                                            r_bs, out.data_ptr(), y_bs, B, Ci, Co, H, W, ks,
@@ -239,9 +333,23 @@ def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=
                 shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
             raise ValueError("groupnorm: scale/shift must be [B,C] with unit inner stride")
         ss_bs = scale.stride(0)
+    st = _stream()
+    hs = _find_stats(x, G)
+    _drop_stats(out)
+    if hs is not None:   # the producer conv left the statistics: one pass over the tensor
+        import ctypes as C_
+        from ._lib import OctStats
+
+        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots) for h in hs]
+        with _Timed("groupnorm", 8.0 * B * C * H * W):
+            check(lib().lc_groupnorm_apply_os(x.data_ptr(), x_bs, C_.byref(keep[0]),
+                                              C_.byref(keep[1]) if len(keep) > 1 else None, _p(gamma),
+                                              _p(beta), _p(scale), _p(shift), ss_bs, out.data_ptr(),
+                                              y_bs, B, C, H, W, G, float(eps), int(act_silu), st),
+                  "lc_groupnorm_apply_os")
+        return out
     n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
     part = _partials(x.device, n)
-    st = _stream()
     with _Timed("groupnorm", 12.0 * B * C * H * W):  # bytes: stats read + apply read + write
         check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, st),
               "lc_groupnorm_stats")
@@ -336,6 +444,7 @@ def resample2x(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None) ->
     y_bs = _bs4(out, "out")
     if tuple(out.shape) != shape:
         raise ValueError("resample: out shape mismatch")
+    _drop_stats(out)
     with _Timed("resample", 4.0 * B * C * H * W * (5.0 if up else 1.25)):
         check(lib().lc_resample2x_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W,
                                       1 if up else -1, _stream()), "lc_resample2x_fwd")
@@ -423,6 +532,7 @@ def pstep(x_t, pred, noise, coef, objective: int, mode: int, out=None) -> torch.
     if out is None:
         out = torch.empty((B, C, H, W), device=x_t.device, dtype=_F32)
     ob = _bs4(out, "out")
+    _drop_stats(out)
     nb = _bs4(noise, "noise") if noise is not None else 0
     _req(coef, "coef")
     if tuple(coef.shape) != (B, 8) or not coef.is_contiguous():
@@ -438,6 +548,7 @@ def copy_into(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     if dst.shape != src.shape:
         raise ValueError("copy_into: shape mismatch")
     B, C, H, W = src.shape
+    _drop_stats(dst)
     check(lib().lc_copy_strided(src.data_ptr(), sb, dst.data_ptr(), db, B, C * H * W, _stream()),
           "lc_copy_strided")
     return dst
@@ -449,6 +560,7 @@ def add_scale(a: torch.Tensor, b: torch.Tensor, scale: float, out=None) -> torch
     if out is None:
         out = torch.empty((B, C, H, W), device=a.device, dtype=_F32)
     ob = _bs4(out, "out")
+    _drop_stats(out)
     check(lib().lc_add_scale(a.data_ptr(), ab, b.data_ptr(), bb, out.data_ptr(), ob, B, C * H * W,
                              float(scale), _stream()), "lc_add_scale")
     return out

@@ -164,6 +164,70 @@ def test_groupnorm(dev, B, C, H, W, G, mode):
     assert rel_l2(y, ref) < 2e-6, rel_l2(y, ref)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks,G,cfg", [
+    (2, 64, 128, 16, 128, 3, 8, 0), (2, 64, 128, 16, 128, 3, 8, 23), (2, 64, 64, 16, 128, 3, 8, 423),
+    (1, 128, 256, 8, 256, 3, 32, 25), (2, 48, 96, 5, 50, 3, 4, 13), (1, 64, 72, 3, 100, 3, 3, 15),
+    (1, 64, 64, 32, 1024, 3, 8, 0), (2, 64, 512, 4, 128, 3, 8, 0), (1, 32, 64, 9, 70, 3, 8, 22),
+    (2, 64, 128, 16, 128, 3, 8, 28),
+])
+def test_groupnorm_from_conv_epilogue_stats(dev, B, Ci, Co, H, W, ks, G, cfg):
+    """The octet statistics emitted by the pipelined conv's epilogue drive GroupNorm to the same
+    result as the statistics pass over the tensor -- every pipelined tile shape, ragged planes,
+    persistent tiles, an output with a large mean (pivot-shifted sums)."""
+    from lidarcrafter_amd import ops as K
+
+    x = seeded_randn(B, Ci, H, W, seed=81).to(dev)
+    w = (seeded_randn(Co, Ci, ks, ks, seed=82) / (Ci * ks * ks) ** 0.5).to(dev)
+    b = (seeded_randn(Co, seed=83) + 300.0).to(dev)         # |mean| >> std
+    res = seeded_randn(B, Co, H, W, seed=84).to(dev)
+    gamma, beta = seeded_randn(Co, seed=85).to(dev), seeded_randn(Co, seed=86).to(dev)
+    ss = seeded_randn(B, 2 * Co, seed=87).to(dev) * 0.3
+    y = K.conv2d_ring(x, K.PackedConv(), w, b, res=res, out_scale=0.7, tile_cfg=cfg, emit_stats=True)
+    assert K._find_stats(y, G) is not None
+    got = K.groupnorm(y, G, 1e-6, gamma, beta, ss[:, :Co], ss[:, Co:], act_silu=True)
+    y2 = y.clone()                                           # new object: no statistics attached
+    assert K._find_stats(y2, G) is None
+    ref = K.groupnorm(y2, G, 1e-6, gamma, beta, ss[:, :Co], ss[:, Co:], act_silu=True)
+    assert rel_l2(got, ref) < 5e-6, rel_l2(got, ref)
+    yd = y.double().reshape(B, G, -1)
+    mu, var = yd.mean(-1), yd.var(-1, unbiased=False)
+    exact = ((yd - mu[..., None]) / (var[..., None] + 1e-6).sqrt()).reshape(B, Co, H, W)
+    exact = (exact * gamma.double()[None, :, None, None] + beta.double()[None, :, None, None]) * \
+        (1 + ss[:, :Co].double())[..., None, None] + ss[:, Co:].double()[..., None, None]
+    exact = exact * torch.sigmoid(exact)
+    assert rel_l2(got, exact.float()) < 2e-4, rel_l2(got, exact.float())   # fp32 y at mean 300
+    # group sizes that are not whole octets fall back to the statistics pass
+    if (Co // 3) % 8:
+        assert K._find_stats(y, 3) is None
+
+
+def test_groupnorm_concat_segments_and_invalidation(dev):
+    """Two producers write the halves of a concat buffer (different tile shapes -> different slot
+    counts); GroupNorm over the buffer folds both segments; overwriting a half drops them."""
+    from lidarcrafter_amd import ops as K
+
+    B, C, H, W, G = 2, 64, 16, 128, 8
+    cat = torch.empty(B, 2 * C, H, W, device=dev)
+    x = seeded_randn(B, 32, H, W, seed=91).to(dev)
+    w1 = (seeded_randn(C, 32, 3, 3, seed=92) / 17.0).to(dev)
+    w2 = (seeded_randn(C, 32, 3, 3, seed=93) / 17.0).to(dev)
+    K.conv2d_ring(x, K.PackedConv(), w1, None, out=cat[:, :C], tile_cfg=23, emit_stats=True)
+    K.conv2d_ring(x, K.PackedConv(), w2, None, out=cat[:, C:], tile_cfg=13, emit_stats=True)
+    hs = K._find_stats(cat, G)
+    assert hs is not None and len(hs) == 2 and hs[0].slots != hs[1].slots
+    got = K.groupnorm(cat, G, 1e-6, act_silu=False)
+    ref = K.groupnorm(cat.clone(), G, 1e-6, act_silu=False)
+    assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
+    assert K._find_stats(cat[:, :C], G) is not None        # a half on its own also resolves
+    K.resample2x(torch.zeros(B, C, H // 2, W // 2, device=dev), up=True, out=cat[:, C:])
+    assert K._find_stats(cat, G) is None and K._find_stats(cat[:, :C], G) is not None
+    K.conv2d_ring(x, K.PackedConv(), w1, None, out=cat[:, :C])       # no emission: stats dropped
+    assert K._find_stats(cat[:, :C], G) is None
+    # the 2-blocks/CU kernel emits none: the request is a no-op and GroupNorm takes the old route
+    y = K.conv2d_ring(x[:, :8].contiguous(), K.PackedConv(), w1[:, :8].contiguous(), None, emit_stats=True)
+    assert K._find_stats(y, G) is None
+
+
 def test_groupnorm_large_mean(dev):
     """fp64 partial sums: no catastrophic cancellation when |mean| >> std."""
     from lidarcrafter_amd import ops as K
