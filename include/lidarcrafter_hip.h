@@ -67,15 +67,26 @@ int lc_conv2d_ring_fwd(const float* x, int64_t x_bs, const float* wp, const floa
 int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks);
 int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
                               lc_stream_t s);
+/* Producer-side GroupNorm statistics of one channel segment: the entries a conv wrote through
+ * gn_ostats_out (below), consumed by lc_groupnorm_apply_os or by the next conv's fused input norm. */
+typedef struct lc_oct_stats {
+    const float* p;     /* [B, channels/8, slots, 4] */
+    int channels, slots;
+} lc_oct_stats;
 /* Input normalisation straight from the statistics (no lc_groupnorm_coeffs launch): the partials
  * of lc_groupnorm_stats over the conv's input plus the GroupNorm / AdaGN parameters; every block
- * derives the rows of its sample in its prologue with the arithmetic of lc_groupnorm_coeffs. */
+ * derives the rows of its sample in its prologue with the arithmetic of lc_groupnorm_coeffs.
+ * Alternatively (partials == NULL, os0 != NULL) from the octet statistics the input's producer(s)
+ * emitted -- then no statistics pass over the input exists at all; os0 covers channels
+ * [0, os0->channels), os1 (may be NULL) the rest, as in lc_groupnorm_apply_os; needs
+ * (Ci/G) % 8 == 0, every group inside one segment and G <= 128 (LC_EUNSUP otherwise). */
 typedef struct lc_gn_stats_input {
-    const double* partials;   /* lc_groupnorm_stats(x, ...) of THIS conv's input */
+    const double* partials;   /* lc_groupnorm_stats(x, ...) of THIS conv's input, or NULL */
     int G, nch;               /* groups; chunks per group = partials_elems / (2 * B * G) */
     float eps;
     const float *gamma, *beta, *scale, *shift;   /* each may be NULL, as in lc_groupnorm_apply */
     int64_t ss_bs;
+    const lc_oct_stats *os0, *os1;               /* used when partials == NULL */
 } lc_gn_stats_input;
 
 int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, const void* wp_lo,
@@ -130,10 +141,6 @@ int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials, con
  * [0, s0->channels), s1 (may be NULL) the rest.  Needs (C/G) % 8 == 0 and every group inside one
  * segment (LC_EUNSUP otherwise: use stats + apply).  The fold is fp64 around one common pivot per
  * group in a fixed order (deterministic). */
-typedef struct lc_oct_stats {
-    const float* p;     /* [B, channels/8, slots, 4] */
-    int channels, slots;
-} lc_oct_stats;
 int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_stats* s0, const lc_oct_stats* s1,
                           const float* gamma, const float* beta, const float* scale,
                           const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B, int C,

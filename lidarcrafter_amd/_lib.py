@@ -18,21 +18,21 @@ class CmOperand(C.Structure):
 _op = C.POINTER(CmOperand)
 
 
-class GnStatsInput(C.Structure):
-    """struct lc_gn_stats_input: GroupNorm statistics + parameters for the conv's fused input norm."""
-    _fields_ = [("partials", vp), ("G", i32), ("nch", i32), ("eps", f32), ("gamma", vp), ("beta", vp),
-                ("scale", vp), ("shift", vp), ("ss_bs", i64)]
-
-
-_gs = C.POINTER(GnStatsInput)
-
-
 class OctStats(C.Structure):
     """struct lc_oct_stats: producer-side GroupNorm statistics of one channel segment."""
     _fields_ = [("p", vp), ("channels", i32), ("slots", i32)]
 
 
 _os = C.POINTER(OctStats)
+
+
+class GnStatsInput(C.Structure):
+    """struct lc_gn_stats_input: GroupNorm statistics + parameters for the conv's fused input norm."""
+    _fields_ = [("partials", vp), ("G", i32), ("nch", i32), ("eps", f32), ("gamma", vp), ("beta", vp),
+                ("scale", vp), ("shift", vp), ("ss_bs", i64), ("os0", _os), ("os1", _os)]
+
+
+_gs = C.POINTER(GnStatsInput)
 
 # name -> (restype, argtypes); mirrors include/lidarcrafter_hip.h one to one
 SIGNATURES = {

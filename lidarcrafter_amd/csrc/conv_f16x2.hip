@@ -59,7 +59,10 @@ struct ConvArgsH {
     int Cgn, gn_silu;
     // ... or the statistics themselves (lc_groupnorm_stats partials): the block derives the rows of
     // its sample in its prologue, so no lc_groupnorm_coeffs launch sits between stats and conv
-    lc_gn_stats_input gs;
+    lc_gn_stats_input gs;     // (os0 / os1 are host pointers: the kernels read seg[] instead)
+    // ... or the octet statistics the input's producer(s) emitted (gs.partials == NULL):
+    // seg[0] covers channels [0, seg[0].channels), seg[1] the rest
+    struct OctSeg { const f32x4* p; int channels, slots; } seg[2];
     int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles of one sample
     int vert;  // 1: the block walks its tpb tiles down H (W-neighbours run concurrently), 0: along W
     int xcd;   // 1: blockIdx.x is remapped so that each XCD owns a contiguous range of tiles
@@ -82,7 +85,16 @@ __device__ __forceinline__ f32x4 gn_row_from_stats(const lc_gn_stats_input& gs, 
     const int cpg = C / gs.G, g = c / cpg;
     const double* pp = gs.partials + ((long long)b * gs.G + g) * gs.nch * 2;
     double s_ = 0.0, q_ = 0.0;
-    for (int k = 0; k < gs.nch; ++k) { s_ += pp[2 * k]; q_ += pp[2 * k + 1]; }
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const f64x2* pv = reinterpret_cast<const f64x2*>(pp);
+    for (int k0 = 0; k0 < gs.nch; k0 += 8) {                    // 8 loads in flight, same add order
+        f64x2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = k0 + k < gs.nch ? pv[k0 + k] : f64x2{0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k0 + k < gs.nch) { s_ += v[k].x; q_ += v[k].y; }
+    }
     const double n = (double)cpg * (double)HW;
     const double dm = s_ / n;
     double var = q_ / n - dm * dm;
@@ -94,6 +106,60 @@ __device__ __forceinline__ f32x4 gn_row_from_stats(const lc_gn_stats_input& gs, 
     const float sh = gs.shift ? gs.shift[b * gs.ss_bs + c] : 0.0f;
     r.x = mu; r.y = rstd * ga * sc; r.z = be * sc + sh;
     return r;
+}
+
+// The same rows from the PRODUCER's octet statistics (the fold of gn_apply_os_kernel, norm.hip):
+// wave w folds the entries of groups w, w + nwaves, ... in fp64 around the group's first pivot,
+// then every thread builds the rows of its channels.  All NT threads of the block call this.
+constexpr int GN_MAX_G = 128;
+template <int NT>
+__device__ __forceinline__ void gn_rows_from_ostats(const ConvArgsH& a, int b, int tid, f32x4* ctab,
+                                                    float2* gtab) {
+    const int G = a.gs.G, cpg = a.Ci / G, lane = tid & 63;
+    for (int g = tid >> 6; g < G; g += NT / 64) {
+        const int cg0 = g * cpg;
+        const bool s1 = cg0 >= a.seg[0].channels;
+        const int slots = s1 ? a.seg[1].slots : a.seg[0].slots;
+        const f32x4* e =
+            s1 ? a.seg[1].p + ((long long)b * (a.seg[1].channels >> 3) + ((cg0 - a.seg[0].channels) >> 3)) * slots
+               : a.seg[0].p + ((long long)b * (a.seg[0].channels >> 3) + (cg0 >> 3)) * slots;
+        const int n_ent = (cpg >> 3) * slots;
+        const double P0 = (double)e[0].x;
+        double N = 0.0, S = 0.0, Q = 0.0;
+        for (int base = lane; base < n_ent; base += 64 * 8) {   // 8 loads in flight per lane
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = base + 64 * k < n_ent ? e[base + 64 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                       // an absent entry (n = 0) adds nothing
+                const double n = v[k].y, d = (double)v[k].x - P0, s_ = v[k].z;
+                N += n;
+                S += s_ + n * d;
+                Q += (double)v[k].w + d * (2.0 * s_ + n * d);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            N += __shfl_xor(N, o, 64); S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64);
+        }
+        const double m = N > 0.0 ? S / N : 0.0;
+        double var = N > 0.0 ? Q / N - m * m : 0.0;
+        if (var < 0.0) var = 0.0;
+        if (lane == 0) gtab[g] = float2{(float)(P0 + m), (float)(1.0 / sqrt(var + (double)a.gs.eps))};
+    }
+    __syncthreads();
+    for (int c = tid; c < a.Cgn; c += NT) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (c < a.Ci) {
+            const float2 ms = gtab[c / cpg];
+            const float ga = a.gs.gamma ? a.gs.gamma[c] : 1.0f, be = a.gs.beta ? a.gs.beta[c] : 0.0f;
+            const float sc = a.gs.scale ? 1.0f + a.gs.scale[b * a.gs.ss_bs + c] : 1.0f;
+            const float sh = a.gs.shift ? a.gs.shift[b * a.gs.ss_bs + c] : 0.0f;
+            r.x = ms.x; r.y = ms.y * ga * sc; r.z = be * sc + sh;
+        }
+        ctab[c] = r;
+    }
 }
 
 __device__ __forceinline__ float gn_act(float x, const f32x4 c, int silu) {
@@ -140,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     constexpr int KS = 2 * HALO + 1;
     __shared__ half8 lds[2 * XU + 2 * WU];
     __shared__ f32x4 ctab[GN_MAX_C];   // fused input GroupNorm rows (mu, A, B, 0) of sample b
+    __shared__ float2 gtab[GN_MAX_G];  // (mean, rstd) per group while the rows are derived
     half8* xh = lds;
     half8* xl = lds + XU;
     half8* wh = lds + 2 * XU;
@@ -245,6 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     if (a.gn) {
         if (a.gs.partials) {
             for (int i = tid; i < a.Cgn; i += 256) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
+        } else if (a.seg[0].p) {
+            gn_rows_from_ostats<256>(a, b, tid, ctab, gtab);
         } else {
             const f32x4* g = a.gn + (long long)b * a.Cgn;
             for (int i = tid; i < a.Cgn; i += 256) ctab[i] = g[i];
@@ -374,6 +443,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     constexpr int BUF = 2 * XUP + 2 * WUP;             // half8 units per LDS buffer
     __shared__ half8 lds[2 * BUF];
     __shared__ f32x4 ctab[GN_MAX_C];                   // fused input GroupNorm rows of sample b
+    __shared__ float2 gtab[GN_MAX_G];                  // (mean, rstd) per group while they are derived
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -449,14 +519,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const long long w_chunk = (long long)CB * a.Cop;    // unit stride between K chunks
 
     const bool use_gn = a.gn != nullptr;
-    if (use_gn) {
-        if (a.gs.partials) {
-            for (int i = tid; i < a.Cgn; i += NT) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
-        } else {
-            const f32x4* g = a.gn + (long long)b * a.Cgn;
-            for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
-        }
-    }
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
         for (int i = 0; i < NXU; ++i)
@@ -589,7 +651,17 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     // prologue: chunk 0 -> cur
     load_x(xr, 0);
     load_w(wr, 0);
-    if (use_gn) __syncthreads();                        // ctab visible
+    if (use_gn) {   // rows of the fused input norm, derived while the chunk-0 loads are in flight
+        if (a.gs.partials) {
+            for (int i = tid; i < a.Cgn; i += NT) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
+        } else if (a.seg[0].p) {
+            gn_rows_from_ostats<NT>(a, b, tid, ctab, gtab);
+        } else {
+            const f32x4* g = a.gn + (long long)b * a.Cgn;
+            for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
+        }
+        __syncthreads();                                // ctab visible
+    }
 #pragma unroll
     for (int i = 0; i < NXU; ++i) store_x(cur, xr, i, 0);
 #pragma unroll
@@ -872,12 +944,23 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.tiles_h = a.tiles_w = 0;
     a.gn = reinterpret_cast<const f32x4*>(gn_coeffs);
     a.Cgn = gn_cpad; a.gn_silu = gn_silu;
-    a.gs = lc_gn_stats_input{nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0};
+    a.gs = lc_gn_stats_input{nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    a.seg[0] = a.seg[1] = ConvArgsH::OctSeg{nullptr, 0, 0};
     if (gn_stats) {
-        if (gn_coeffs || !gn_stats->partials || gn_stats->G <= 0 || Ci % gn_stats->G ||
-            gn_stats->nch <= 0)
-            return LC_EINVAL;
+        if (gn_coeffs || gn_stats->G <= 0 || Ci % gn_stats->G) return LC_EINVAL;
+        if (gn_stats->partials) {
+            if (gn_stats->nch <= 0) return LC_EINVAL;
+        } else {
+            const lc_oct_stats *s0 = gn_stats->os0, *s1 = gn_stats->os1;
+            if (!s0 || !s0->p || s0->channels <= 0 || s0->slots <= 0) return LC_EINVAL;
+            if (s1 && (!s1->p || s1->channels <= 0 || s1->slots <= 0)) return LC_EINVAL;
+            const int c0 = s0->channels, c1 = s1 ? s1->channels : 0, cpg = Ci / gn_stats->G;
+            if (c0 + c1 != Ci || cpg % 8 || c0 % cpg || gn_stats->G > GN_MAX_G) return LC_EUNSUP;
+            a.seg[0] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s0->p), c0, s0->slots};
+            if (s1) a.seg[1] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s1->p), c1, s1->slots};
+        }
         a.gs = *gn_stats;
+        a.gs.os0 = a.gs.os1 = nullptr;
         a.gn = reinterpret_cast<const f32x4*>(x);   // non-null marker: "normalise the input"
         a.Cgn = gn_cpad > 0 ? gn_cpad : (Ci + 15) / 16 * 16;
     }

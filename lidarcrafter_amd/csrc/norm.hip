@@ -163,12 +163,18 @@ __global__ __launch_bounds__(256) void gn_apply_os_kernel(
     const int n_ent = (cpg >> 3) * slots;
     const double P0 = (double)e[0].x;
     double N = 0.0, S = 0.0, Q = 0.0;
-    for (int i = threadIdx.x; i < n_ent; i += 256) {
-        const f32x4 v = e[i];
-        const double n = v.y, d = (double)v.x - P0, s_ = v.z;
-        N += n;
-        S += s_ + n * d;
-        Q += (double)v.w + d * (2.0 * s_ + n * d);
+    for (int base = threadIdx.x; base < n_ent; base += 256 * 4) {   // 4 loads in flight per thread
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = base + 256 * k < n_ent ? e[base + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // an absent entry (n = 0) adds nothing
+            const double n = v[k].y, d = (double)v[k].x - P0, s_ = v[k].z;
+            N += n;
+            S += s_ + n * d;
+            Q += (double)v[k].w + d * (2.0 * s_ + n * d);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

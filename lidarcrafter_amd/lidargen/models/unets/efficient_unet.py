@@ -97,15 +97,17 @@ class ResidualBlock(nn.Module):
         self._scale_f = float(scale)
 
     def forward(self, x, emb=None, scale_shift=None, out=None):
-        if K.fuse_gn(self.conv1.out_channels):   # GN -> SiLU -> conv: stats pass + conv only
-            h = self.conv1(x, gn_coeffs=self.norm1.coeffs(x))
+        # every conv whose output feeds a GroupNorm leaves octet statistics of what it stores
+        if K.fuse_gn(self.conv1.out_channels):   # GN -> SiLU -> conv: (producer stats +) conv only
+            h = self.conv1(x, gn_coeffs=self.norm1.coeffs(x), emit_stats=True)
             c2 = (self.norm2.coeffs(h, emb, scale_shift=scale_shift) if self.has_emb
                   else self.norm2.coeffs(h))
             if isinstance(self.skip, nn.Identity):
                 sk = x
             else:
                 sk = self.skip(x)
-            return self.conv2(h, res=sk, out=out, out_scale=self._scale_f, gn_coeffs=c2)
+            return self.conv2(h, res=sk, out=out, out_scale=self._scale_f, gn_coeffs=c2,
+                              emit_stats=True)
         # unfused GroupNorms (wide layers): the producing convs leave the statistics, the
         # GroupNorm is a single apply pass
         a = self.norm1(x, act_silu=True)
@@ -154,8 +156,7 @@ class Block(nn.Module):
         if has_attn:
             h = self.self_attn_block(h, out=out if not has_up else None)
         if has_up:   # feeds the next block's first GroupNorm (through the concat buffer)
-            h = self.upsample[1](self.upsample[0](h), out=out,
-                                 emit_stats=not K.fuse_gn(self.upsample[1].out_channels))
+            h = self.upsample[1](self.upsample[0](h), out=out, emit_stats=True)
         return h
 
 

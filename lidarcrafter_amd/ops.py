@@ -366,13 +366,18 @@ class GnStats:
 
     __slots__ = ("shape", "_struct", "_keep")
 
-    def __init__(self, shape, part, G, nch, eps, gamma, beta, scale, shift, ss_bs):
-        from ._lib import GnStatsInput
+    def __init__(self, shape, part, G, nch, eps, gamma, beta, scale, shift, ss_bs, oct_handles=None):
+        import ctypes as C
+
+        from ._lib import GnStatsInput, OctStats
 
         self.shape = shape
-        self._keep = (part, gamma, beta, scale, shift)
-        self._struct = GnStatsInput(part.data_ptr(), G, nch, float(eps), _p(gamma), _p(beta),
-                                    _p(scale), _p(shift), ss_bs)
+        segs = [OctStats(h.buf.data_ptr(), h.channels, h.slots) for h in (oct_handles or ())]
+        self._keep = (part, gamma, beta, scale, shift, oct_handles, segs)
+        self._struct = GnStatsInput(_p(part), G, nch, float(eps), _p(gamma), _p(beta),
+                                    _p(scale), _p(shift), ss_bs,
+                                    C.pointer(segs[0]) if segs else None,
+                                    C.pointer(segs[1]) if len(segs) > 1 else None)
 
     def byref(self):
         import ctypes as C
@@ -382,7 +387,9 @@ class GnStats:
 
 def groupnorm_stats(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=None,
                     shift=None) -> GnStats:
-    """Statistics pass only (one launch); the consumer conv turns them into rows in its prologue."""
+    """Statistics for a conv that normalises its input on the fly: the producer's octet statistics
+    when `x` carries them (no launch at all), else one statistics pass; the consumer conv turns
+    either into rows in its prologue."""
     x_bs = _bs4(x, "x")
     B, C, H, W = x.shape
     if C % G:
@@ -397,6 +404,9 @@ def groupnorm_stats(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, 
     for n_, t_ in (("gamma", gamma), ("beta", beta)):
         if t_ is not None:
             _req(t_, n_)
+    hs = _find_stats(x, G) if G <= 128 else None
+    if hs is not None:
+        return GnStats((B, C, H, W), None, G, 0, eps, gamma, beta, scale, shift, ss_bs, hs)
     n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
     part = torch.empty((n,), device=x.device, dtype=torch.float64)   # owned by the handle
     with _Timed("groupnorm", 4.0 * B * C * H * W):

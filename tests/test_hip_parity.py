@@ -228,6 +228,42 @@ def test_groupnorm_concat_segments_and_invalidation(dev):
     assert K._find_stats(y, G) is None
 
 
+@pytest.mark.parametrize("cfg", [0, 3, 5, 13, 23, 25, 28, 223])
+@pytest.mark.parametrize("B,C,H,W,G,ks", [(2, 64, 16, 128, 8, 3), (1, 64, 32, 1024, 8, 3),
+                                          (2, 64, 5, 72, 4, 3), (2, 64, 8, 64, 8, 1)])
+def test_conv_fused_groupnorm_from_producer_stats(dev, B, C, H, W, G, ks, cfg):
+    """The consumer conv derives its fused-GroupNorm rows from the octet statistics its input's
+    producers emitted (no statistics pass): same result as the two-pass route, for a single
+    producer and for a concat of two (different slot counts), with AdaGN scale/shift."""
+    from lidarcrafter_amd import ops as K
+
+    if ks == 1 and cfg not in (0, 3, 5):
+        pytest.skip("1x1 convs run on the 2-blocks/CU kernel")
+    if ks == 3 and cfg == 28:
+        Co = 32
+    else:
+        Co = 64
+    x = seeded_randn(B, 32, H, W, seed=191).to(dev)
+    w1 = (seeded_randn(C, 32, 3, 3, seed=192) / 17.0).to(dev)
+    w2 = (seeded_randn(C, 32, 3, 3, seed=193) / 11.0).to(dev)
+    bias1 = (seeded_randn(C, seed=194) * 2.0).to(dev)      # a mean far from the pivot
+    cat = torch.empty(B, 2 * C, H, W, device=dev)
+    K.conv2d_ring(x, K.PackedConv(), w1, bias1, out=cat[:, :C], tile_cfg=23, emit_stats=True)
+    K.conv2d_ring(x, K.PackedConv(), w2, None, out=cat[:, C:], tile_cfg=13, emit_stats=True)
+    for src, Ci, GG in ((cat[:, :C], C, G), (cat, 2 * C, 2 * G)):
+        wc = (seeded_randn(Co, Ci, ks, ks, seed=195) / (Ci * ks * ks) ** 0.5).to(dev)
+        ga, be = (1 + 0.1 * seeded_randn(Ci, seed=196)).to(dev), (0.1 * seeded_randn(Ci, seed=197)).to(dev)
+        ss = (0.3 * seeded_randn(B, 2 * Ci, seed=198)).to(dev)
+        st = K.groupnorm_stats(src, GG, 1e-6, ga, be, ss[:, :Ci], ss[:, Ci:])
+        assert st._struct.partials is None and st._struct.os0      # took the producer's statistics
+        got = K.conv2d_ring(src, K.PackedConv(), wc, None, tile_cfg=cfg, gn_coeffs=st, gn_silu=True)
+        ref_in = src.clone()                                      # a copy carries no statistics
+        st_ref = K.groupnorm_stats(ref_in, GG, 1e-6, ga, be, ss[:, :Ci], ss[:, Ci:])
+        assert st_ref._struct.partials is not None
+        ref = K.conv2d_ring(ref_in, K.PackedConv(), wc, None, tile_cfg=cfg, gn_coeffs=st_ref, gn_silu=True)
+        assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
+
+
 def test_groupnorm_large_mean(dev):
     """fp64 partial sums: no catastrophic cancellation when |mean| >> std."""
     from lidarcrafter_amd import ops as K
