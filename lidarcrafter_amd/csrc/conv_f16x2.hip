@@ -19,6 +19,10 @@
 
 #include "common.h"
 
+#ifndef LC_EPI_MODE
+#define LC_EPI_MODE 2   // 0 plain stores, 2 write-through (sc1) stores (developer A/B)
+#endif
+
 namespace {
 
 // Output store of the conv epilogues.  Mode 2 marks the store write-through (sc1): the lines do
@@ -34,9 +38,6 @@ __device__ __forceinline__ void epi_store(float* p, float v) {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#ifndef LC_EPI_MODE
-#define LC_EPI_MODE 2   // 0 plain stores, 2 write-through (sc1) stores (developer A/B)
-#endif
 #ifndef LC_ABLATE
 #define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
 #endif
