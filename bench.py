@@ -171,7 +171,7 @@ def main():
         split = K.CONV_PRECISION == "f16x2"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from a separate PMC pass
-        tpath = os.path.join(ROOT, "profiles", "r01_f_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
         if split and BATCH_PER_GPU == 8 and os.path.exists(tpath):
             traffic = round(json.load(open(tpath))["conv3x3_bytes_per_launch"])
         roof = {"bound": "mfma",
@@ -179,7 +179,7 @@ def main():
                           " (all tile instantiations)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_source": ("profiles/r01_f_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 "
+                "traffic_source": ("profiles/r01_i_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 "
                                    "gfx950 correction) + WRITE_SIZE, separate passes, same workload"
                                    if traffic else None),
                 "note": ("achieved counts ALGORITHMIC flops (2*MACs); the f16x2 split issues 3 "

@@ -76,21 +76,21 @@ class ResBlock(TimestepBlock):
         if self.updown:      # GN -> SiLU -> resample -> conv: the norm cannot ride on the conv
             a = self.op(self.in_layers[0](x, act_silu=True))
             x = self.op(x)
-            h = self.in_layers[2](a)
+            h = self.in_layers[2](a, emit_stats=True)
         elif fuse:
             a = None
-            h = self.in_layers[2](x, gn_coeffs=gn32_coeffs(self.in_layers[0], x))
+            h = self.in_layers[2](x, gn_coeffs=gn32_coeffs(self.in_layers[0], x), emit_stats=True)
         else:
             a = self.in_layers[0](x, act_silu=True)
-            h = self.in_layers[2](a)
+            h = self.in_layers[2](a, emit_stats=True)   # statistics for out_layers[0]
         if fuse:
             sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
-            return self.out_layers[3](h, res=sk, out=out,
+            return self.out_layers[3](h, res=sk, out=out, emit_stats=True,
                                       gn_coeffs=gn32_coeffs(self.out_layers[0], h, scale, shift))
         a2 = self.out_layers[0](h, scale, shift, act_silu=True,
                                 out=a if a is not None and a.shape == h.shape else None)
         sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
-        return self.out_layers[3](a2, res=sk, out=out)
+        return self.out_layers[3](a2, res=sk, out=out, emit_stats=True)   # ... for the next block's norm
 
 
 class ObjectAwareCrossAttention(nn.Module):
