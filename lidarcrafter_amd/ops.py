@@ -240,7 +240,14 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 emit_stats: bool = False) -> torch.Tensor:
     """y = (conv_ring(x', W) + bias [+ res]) * out_scale with x' = x, or -- when `gn_coeffs`
     (from `groupnorm_coeffs`) is given -- x' = silu?(GroupNorm(x)) applied on the fly while the
-    input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference."""
+    input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference.
+
+    emit_stats: the conv also leaves per-octet GroupNorm statistics of what it stores, attached to
+    the output tensor object; a following `groupnorm` / `groupnorm_stats` of that tensor (or of a
+    concat buffer whose halves both carry them) then skips its statistics pass.  Every wrapper of
+    this module that writes into an `out=` tensor forgets the statistics of what it overwrites;
+    a caller who modifies such a tensor with a torch in-place op must not request them (inference
+    tensors carry no version counter that could catch it)."""
     x_bs = _bs4(x, "x")
     prec = precision or CONV_PRECISION
     if gn_coeffs is not None and prec != "f16x2":
