@@ -61,3 +61,82 @@ def test_product_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of the header's structs have the C compiler's size and field offsets."""
+    import ctypes as C
+    import subprocess
+
+    from lidarcrafter_amd import _lib
+
+    structs = {"lc_cm_operand": _lib.CmOperand, "lc_oct_stats": _lib.OctStats,
+               "lc_gn_stats_input": _lib.GnStatsInput}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "lidarcrafter_hip.h"\n'
+                   "int main(void) {\n" + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for line, (cname, cls) in zip(out, structs.items()):
+        got = line.split()
+        assert got[0] == cname
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(v) for v in got[1:]] == want, (cname, got, want)
+
+
+def test_stats_slots_helper():
+    """lc_conv2d_ring_f16x2_stats_slots is host-only: entries per (sample, octet) for the tile the
+    heuristic picks, 0 where the chosen kernel emits none."""
+    from lidarcrafter_amd import _lib
+
+    h = _lib.lib()
+    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 3, 0) == 128 * 4   # 4x64 tiles, 4 px waves
+    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 1, 0) == 0         # 1x1: 2-blocks/CU kernel
+    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 2, 64, 32, 1024, 3, 0) == 0          # Ci < 24: likewise
+    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 62, 32, 1024, 3, 0) == 0         # Co % 8
+
+
+def test_producer_stats_bookkeeping():
+    """Host logic of the producer-side GroupNorm statistics (ops._attach_stats / _find_stats /
+    _drop_stats) on CPU tensors: channel slices of a concat buffer, two-segment lookup,
+    invalidation by overlap, refusal of shapes / group sizes the kernels cannot fold."""
+    import torch
+
+    from lidarcrafter_amd import ops as K
+
+    B, H, W = 2, 4, 8
+    buf = torch.zeros(B, 128, H, W)
+    lo, hi = buf[:, :64], buf[:, 64:]
+    h0 = K._OctStatsHandle(torch.zeros(1), 64, 3, (B, H, W))
+    h1 = K._OctStatsHandle(torch.zeros(1), 64, 5, (B, H, W))
+    K._attach_stats(lo, h0)
+    assert K._find_stats(buf, 8) is None                       # second half unknown
+    K._attach_stats(hi, h1)
+    assert K._find_stats(buf, 8) == (h0, h1)
+    assert K._find_stats(buf[:, :64], 8) == (h0,)              # a fresh view of the same range
+    assert K._find_stats(buf[:, 64:], 4) == (h1,)
+    assert K._find_stats(buf, 32) is None                      # 4 channels per group: not octets
+    assert K._find_stats(buf, 1) is None                       # group would straddle the segments
+    assert K._find_stats(buf[:, 32:96], 8) is None             # not a recorded range
+    assert K._find_stats(buf[:, :, :2], 8) is None             # not a plain channel slice
+    K._drop_stats(buf[:, 60:70])                               # overlaps both ranges
+    assert K._find_stats(lo, 8) is None and K._find_stats(hi, 8) is None
+    K._attach_stats(lo, h0)
+    K._attach_stats(hi, h1)
+    K._drop_stats(hi)
+    assert K._find_stats(lo, 8) == (h0,) and K._find_stats(buf, 8) is None
+    other = torch.zeros(B, 64, H, 2 * W)
+    K._attach_stats(other, h0)                                 # handle of a different plane shape
+    assert K._find_stats(other, 8) is None
+    own = torch.zeros(B, 64, H, W)
+    K._attach_stats(own, h0)
+    assert K._find_stats(own, 8) == (h0,)
+    K._drop_stats(own)
+    assert K._find_stats(own, 8) is None
