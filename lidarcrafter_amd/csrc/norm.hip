@@ -295,6 +295,9 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
     const long long HW = (long long)H * W;
     int slabs = (int)((HW + 4095) / 4096);
     if (slabs < 1) slabs = 1;
+    // every block folds its group's entries (hundreds of 16-byte loads + a reduction) before it
+    // streams: give it as long a slab as possible while >= 2048 blocks remain
+    while (slabs % 2 == 0 && (long long)B * C * (slabs / 2) >= 2048) slabs /= 2;
     int cpb = 1;
     while (cpb * 2 <= cpg && cpg % (cpb * 2) == 0 && HW * cpb * 2 <= 4096 &&
            (long long)B * (C / (cpb * 2)) * slabs >= 512)
