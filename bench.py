@@ -198,7 +198,7 @@ def main():
         cpu = None if args.no_cpu_baseline else cpu_baseline()
         steps_per_s = world * args.steps / dt
         line = {
-            "metric": "denoising-steps/sec, nuScenes 32x1024 range image",
+            "metric": "denoising-steps/sec, nuScenes 32\u00d71024 range image, 1/2/4/8 GPU",   # BASELINE.json, verbatim
             "value": round(steps_per_s, 3),
             "unit": f"denoising-steps/s (each step = batch of {BATCH_PER_GPU} frames per GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -140,3 +140,29 @@ def test_producer_stats_bookkeeping():
     assert K._find_stats(own, 8) == (h0,)
     K._drop_stats(own)
     assert K._find_stats(own, 8) is None
+
+
+def test_bench_line_contract():
+    """The committed bench line (profiles/, produced by `python bench.py` on an MI355X) carries every
+    field of the driver's contract, the roofline and the CPU baseline objects."""
+    import glob
+    import json
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))
+    assert paths
+    d = json.load(open(paths[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    # (lines recorded before the metric string was made verbatim say "32x1024" without the GPU list)
+    assert base["metric"].startswith(d["metric"].replace("32x1024", "32\u00d71024"))
+    assert json.dumps(base["metric"]) in open(os.path.join(ROOT, "bench.py")).read()
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3   # steps/s of the job
