@@ -150,12 +150,11 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         # second, instrumented pass: HIP events around every launch of the dominant kernel
-        st2 = ddpm.begin_sampling(BATCH_PER_GPU, max(args.steps, 3), rng=None, mode="ddim",
-                                  x_T=x_T)
-        ddpm.sampling_step(st2)
+        n_prof = min(args.steps, 5)
+        st2 = ddpm.begin_sampling(BATCH_PER_GPU, n_prof + 1, rng=None, mode="ddim", x_T=x_T)
+        ddpm.sampling_step(st2)                      # one untimed step, then n_prof profiled ones
         torch.cuda.synchronize()
         K.PROFILE = []
-        n_prof = min(args.steps, 5)
         for _ in range(n_prof):
             ddpm.sampling_step(st2)
         torch.cuda.synchronize()
