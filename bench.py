@@ -11,7 +11,7 @@ Weak scaling: every rank owns its own batch of 8 samples (global sample index = 
 only communication is one RCCL all-gather of the finished frames after the loop.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     -- dominant kernel (3x3 ring conv, fp32 MFMA): algorithmic FLOPs / HIP-event time
+  roofline     -- dominant kernel (3x3 ring conv, f16x2-split MFMA): algorithmic FLOPs / HIP-event time
   cpu_baseline -- the CPU oracle (oracle/, torch fp32) timed on this host on a bounded sample.
 """
 from __future__ import annotations
@@ -25,6 +25,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails
+# otherwise); the images export it already, keep it if the launcher's environment was scrubbed
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
