@@ -105,7 +105,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    # (LC_BENCH_FORCE_DIST=1: take the process-group / barrier / all-gather path with one rank too,
+    #  to exercise it on a single-GPU box)
+    dist_on = world > 1 or os.environ.get("LC_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
