@@ -274,6 +274,74 @@ def sec_cond_full():
     save("cond_full", **out)
 
 
+def _strided(x, step=4):
+    """Every `step`-th column of a [..., W] tensor (fixture size: the headline tensors are 2 MB each;
+    samples and rows are all kept, so batch-index / tile-selection mistakes cannot hide)."""
+    return x[..., ::step].contiguous()
+
+
+def sec_c2():
+    """Config C2 at the BENCHMARKED shape (EfficientUNet 32x1024, batch 8): one forward
+    at per-sample log-SNRs and a 50-step DDIM run through the reference sampler
+    (continuous_time.py:237-260), states 1 / 25 / 50.  Columns ::4 of every sample are stored."""
+    eu = R.ref("models.unets.efficient_unet")
+    df = R.ref("models.diffusion")
+    m = _build_uncond(eu, 64, (32, 1024))
+    x = seeded_randn(8, 2, 32, 1024, seed=81)
+    lam = torch.linspace(-6.0, 6.0, 8)
+    with torch.no_grad():
+        y = m(x, lam)
+    out = {"lam": lam, "y_s4": _strided(y), "y_norm": y.flatten(1).norm(dim=1)}
+    ddpm = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval()
+    rng = [torch.Generator().manual_seed(i) for i in range(8)]
+    xs = ddpm.sample(8, 50, progress=False, rng=rng, return_all=True, mode="ddim")
+    for i in (1, 25, 50):
+        out[f"x{i}_s4"] = _strided(xs[i])
+        out[f"x{i}_norm"] = xs[i].flatten(1).norm(dim=1)
+    save("c2_b8", **out)
+
+
+def sec_c3():
+    """Config C3 shard (box-layout-v6, 32x1024, batch 8 per GPU): LayoutUnetV1 forward at per-sample
+    log-SNRs on a synthetic layout batch + a 2-step DDIM run through the reference conditional
+    sampler (continuous_time_cond.py:255-281).  Columns ::4 stored."""
+    df = R.ref("models.diffusion")
+    m, enc = _build_cond((32, 1024), 32, 64)
+    batch = synth_layout_batch(8, 32, 1024, seed=83)
+    x = seeded_randn(8, 2, 32, 1024, seed=84)
+    lam = torch.linspace(-5.0, 5.0, 8)
+    with torch.no_grad():
+        cond = enc(batch)
+        y = m(x, {"time_condition": lam, "other_condition": cond})
+    out = {"lam": lam, "y_s4": _strided(y), "y_norm": y.flatten(1).norm(dim=1)}
+    ddpm = df.CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval()
+    rng = [torch.Generator().manual_seed(40 + i) for i in range(8)]
+    xs = ddpm.sample(batch, 8, 2, progress=False, rng=rng, return_all=True, mode="ddim")
+    out["x2_s4"] = _strided(xs[2])
+    out["x2_norm"] = xs[2].flatten(1).norm(dim=1)
+    save("c3_b8", **out)
+
+
+def sec_c4():
+    """Config C4 shapes: the layout-conditioned denoiser at 64x2048 (`image_size=64`,
+    `feature_map_size=[64,2048]`; attention over 8192 / 2048 tokens + 13 layout keys), width
+    reduced to model_channels=32 so the reference finishes in a minute on 8 cores; both the
+    box-layout (10 cond channels) and the auto-regressive (11 channels, `autoregressive_cond`)
+    input forms (layout_encoder.py:298-302).  B=1, columns ::4 stored."""
+    out = {}
+    for tag, cond_out, n_extra, seed in (("box", 10, 0, 85), ("ar", 11, 1, 87)):
+        m, enc = _build_cond((64, 2048), 64, 32, cond_out=cond_out)
+        batch = synth_layout_batch(1, 64, 2048, seed=seed, n_extra=n_extra)
+        x = seeded_randn(1, 2, 64, 2048, seed=seed + 1)
+        lam = torch.tensor([0.75])
+        with torch.no_grad():
+            cond = enc(batch)
+            y = m(x, {"time_condition": lam, "other_condition": cond})
+        out[f"{tag}_y_s4"] = _strided(y)
+        out[f"{tag}_y_norm"] = y.flatten(1).norm(dim=1)
+    save("c4_64x2048", **out)
+
+
 def synth_boxes(n, pts, seed):
     from lidarcrafter_amd.testing import synth_boxes as f
     return f(n, pts, seed)
