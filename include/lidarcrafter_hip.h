@@ -65,8 +65,25 @@ int lc_conv2d_ring_fwd(const float* x, int64_t x_bs, const float* wp, const floa
  * Arguments otherwise identical to lc_conv2d_ring_fwd.
  * ------------------------------------------------------------------------------------------- */
 int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks);
+/* wmeta: 4 device floats written here, read by lc_conv2d_ring_f16x2_fwd:
+ *   {w_scale, 1 / w_scale, max |w|, 0}.  w_scale is the power of two the weights are multiplied by
+ * before the hi/lo split: 256 while max|w| * 256 lies in [2^5, 2^15] (every trained layer seen so
+ * far), otherwise the power of two that puts max|w| * w_scale into [2^12, 2^13) -- so weights of
+ * any magnitude (1e-30 ... 1e30) keep 22 significant bits and none saturates fp16.  The scale is
+ * derived on the device (no host synchronisation): an all-zero / non-finite tensor keeps 256. */
 int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
-                              lc_stream_t s);
+                              float* wmeta, lc_stream_t s);
+/* Range state of ONE conv layer's input (device memory, 16 bytes, owned by the caller, initialise
+ * with {16, 1/16, 0, 0}).  The kernel multiplies x by x_scale before the fp16 hi/lo split and
+ * publishes the largest |x * x_scale| it staged (after the fused input GroupNorm, if any) into
+ * amax_scaled with atomicMax -- fp16 saturates at 65504, so the caller must treat a launch whose
+ * amax_scaled reached 2^15 as INVALID: pick x_scale = a power of two with max|x| * x_scale ~ 2^12,
+ * reset amax_scaled and run the layer (and everything downstream) again.  lidarcrafter_amd.ops
+ * does exactly that after every forward / sampling run (`range_poll`); nothing saturated is ever
+ * returned silently.  amax_scaled accumulates over launches until the caller zeroes it. */
+typedef struct lc_conv_range {
+    float x_scale, x_unscale, amax_scaled, reserved;
+} lc_conv_range;
 /* Producer-side GroupNorm statistics of one channel segment: the entries a conv wrote through
  * gn_ostats_out (below), consumed by lc_groupnorm_apply_os or by the next conv's fused input norm. */
 typedef struct lc_oct_stats {
@@ -97,6 +114,8 @@ int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, co
                              int gn_silu, const lc_gn_stats_input* gn_stats /* NULL, or instead of
                              gn_coeffs */,
                              float* gn_ostats_out /* NULL or [B, Co/8, slots, 4], see below */,
+                             const float* wmeta /* from lc_pack_conv_weight_f16x2 */,
+                             lc_conv_range* range /* this layer's input range state */,
                              lc_stream_t s);
 /* Output statistics for the NEXT GroupNorm (every GroupNorm input of the denoiser is a conv
  * output, efficient_unet.py:101-108): with gn_ostats_out != NULL every wave of the pipelined kernel

@@ -3,8 +3,17 @@
 //     x*16 = xh + xl,   w*256 = wh + wl      (xh = fp16(x*16), xl = fp16(x*16 - xh), ...)
 // and the product is accumulated in fp32 as  xh*wh + xh*wl + xl*wh  (three
 // v_mfma_f32_32x32x16_f16 per 32x32x16 block; the dropped xl*wl term is 2^-22 relative).
-// The power-of-two pre-scales keep the lo parts in fp16's normal range for activations down to
-// ~1e-2 and weights down to ~1e-3 and are undone exactly (x 2^-12) in the epilogue.
+// The pre-scales are powers of two held in DEVICE memory (lc_conv_range of the layer for x, the
+// header of the packed weights for w): 16 / 256 unless the tensor's magnitude asks for another
+// exponent (RANGE SAFETY below); they are undone exactly in the epilogue.
+//
+// RANGE SAFETY.  fp16 holds |v| < 65504.  Every block tracks the largest |x * x_scale| it stages and
+// publishes it with one atomicMax per wave into lc_conv_range::amax_scaled; the host (ops.range_poll)
+// reads it after the forward / sampling run: a value >= 2^15 (or so small that the lo halves are
+// all subnormal) re-derives the layer's x_scale (target 2^12, sixteen-fold headroom) and the
+// forward is re-run -- a result computed from saturated operands is never handed out silently.
+// Both kernels use ONE split rule (split_pair below): hi = s truncated to 11 significant bits and
+// packed round-toward-zero (saturates at 65504, never inf), lo = fp16(s - hi).
 // Per-product relative error ~5e-7 (fp32 rounding: 6e-8) at 3/16 of the fp32-MFMA instruction
 // cost: 16x rate / 3 passes = 5.3x the fp32 matrix peak.
 //
@@ -38,13 +47,10 @@ __device__ __forceinline__ void epi_store(float* p, float v) {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#ifndef LC_WS_ABL
-#define LC_WS_ABL 0   // ablation of the warp-specialised kernel: 1 no MFMAs, 2 no loads, 4 no stores
-#endif
 #ifndef LC_ABLATE
 #define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
 #endif
-constexpr float X_PRESCALE = 16.0f, W_PRESCALE = 256.0f, OUT_UNSCALE = 1.0f / 4096.0f;
+constexpr float X_PRESCALE_DEFAULT = 16.0f, W_PRESCALE_DEFAULT = 256.0f;
 
 struct ConvArgsH {
     const float* x;
@@ -53,6 +59,8 @@ struct ConvArgsH {
     const float* bias;
     const float* res;
     float* y;
+    lc_conv_range* range;     // x pre-scale of this layer + the running max of what was staged
+    const float* wmeta;       // {w_scale, 1 / w_scale} written by lc_pack_conv_weight_f16x2
     long long x_bs, res_bs, y_bs;
     int B, Ci, Co, H, W, Cib, Cop;
     int tiles_h, tiles_w;
@@ -192,15 +200,35 @@ struct HCfg {
     static_assert(WCO * WPX == 4 || WCO * WPX == 8, "4 or 8 waves");
 };
 
-__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+// THE split rule of both kernels.  s = v * xs;  hi = s truncated to 11 significant bits (exact in
+// fp32) and packed round-toward-zero -- exact below 65504, saturating (never inf) above;
+// lo = fp16(s - hi) (RTNE; subnormal below 2^-14, zero below 2^-25).  `am` accumulates max |s|.
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float v0, float v1, float xs, h2_t& ph, h2_t& pl, float& am) {
+    const float s0 = v0 * xs, s1 = v1 * xs;
+    am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(s0), __builtin_fabsf(s1)));   // v_max3_f32
+    const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+    const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+    ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    f2_t r; r.x = s0 - h0; r.y = s1 - h1;
+    pl = __builtin_convertvector(r, h2_t);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], float xs, half8& hi, half8& lo, float& am) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float s = v[k] * X_PRESCALE;
-        s = fminf(fmaxf(s, -60000.0f), 60000.0f);       // never inf in fp16
-        const _Float16 h = (_Float16)s;
-        hi[k] = h;
-        lo[k] = (_Float16)(s - (float)h);
+    for (int k = 0; k < 8; k += 2) {
+        h2_t ph, pl;
+        split_pair(v[k], v[k + 1], xs, ph, pl, am);
+        hi[k] = ph.x; hi[k + 1] = ph.y; lo[k] = pl.x; lo[k + 1] = pl.y;
     }
+}
+// publish the wave's max |x * x_scale| (am >= 0: unsigned order == float order); a cached read
+// keeps all but the first few blocks of a launch off the atomic
+__device__ __forceinline__ void publish_amax(lc_conv_range* rg, float am, float seen) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0 && am > seen)
+        atomicMax(reinterpret_cast<unsigned*>(&rg->amax_scaled), __float_as_uint(am));
 }
 
 template <class C>
@@ -230,6 +258,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     const int H = a.H, W = a.W;
     const long long HW = (long long)H * W;
     const float* xb = a.x + (long long)b * a.x_bs;
+    const float xs = a.range->x_scale;
+    const float amax_seen = a.range->amax_scaled;
+    const float out_unscale = a.range->x_unscale * a.wmeta[1];
+    float am = 0.0f;
 
     int x_off[NXU];  // (cb << 24 | plane offset) or -1 for padding
 #pragma unroll
@@ -282,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
                     for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu);
                 }
                 half8 hi, lo;
-                split8(xr[i], hi, lo);
+                split8(xr[i], xs, hi, lo, am);
                 xh[e] = hi;
                 xl[e] = lo;
             }
@@ -360,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
         }
     }
 
+    publish_amax(a.range, am, amax_seen);
     float* yb = a.y + (long long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
 #pragma unroll
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + (wco * C::TCO_ + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (pok && co < a.Co) {
-                    float v = acc[i][j][r] * OUT_UNSCALE;
+                    float v = acc[i][j][r] * out_unscale;
                     if (a.bias) v += a.bias[co];
                     if (rb) v += rb[(long long)co * HW + poff];
                     yb[(long long)co * HW + poff] = v * a.out_scale;
@@ -398,22 +431,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
 typedef __attribute__((address_space(3))) void* lds_vptr;
 typedef const __attribute__((address_space(1))) void* gbl_vptr;
 
-__device__ __forceinline__ void split_store(const float (&v)[8], half8* dst_hi, half8* dst_lo) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_store(const float (&v)[8], float xs, half8* dst_hi,
+                                            half8* dst_lo, float& am) {
     half8 hi, lo;
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-        const float s0 = v[k] * X_PRESCALE, s1 = v[k + 1] * X_PRESCALE;
-        // hi = s truncated to 11 significant bits (exact in fp32), lo = s - hi (exact), then
-        // hi converts exactly (round-toward-zero pack never overflows to inf), lo rounds RTNE.
-        const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
-        const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
-        const h2 ph = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-        f2 r; r.x = s0 - h0; r.y = s1 - h1;
-        const h2 pl = __builtin_convertvector(r, h2);
-        hi[k] = ph.x; hi[k + 1] = ph.y; lo[k] = pl.x; lo[k + 1] = pl.y;
-    }
+    split8(v, xs, hi, lo, am);
     *dst_hi = hi;
     *dst_lo = lo;
 }
@@ -486,6 +507,10 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const float* xb = a.x + (long long)b * a.x_bs;
     const unsigned nbytes = (unsigned)a.Ci * (unsigned)HW * 4u;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, nbytes, 0x00020000);
+    const float xs = a.range->x_scale;
+    const float amax_seen = a.range->amax_scaled;
+    const float out_unscale = a.range->x_unscale * a.wmeta[1];
+    float am = 0.0f;
 
     int x_rc[NXU];         // (row << 16 | column) of the unit inside the staged tile
     int x_cb8[NXU];        // 8 * channel-block of the unit, or -1 for padding units (CURRENT tile)
@@ -578,7 +603,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
             for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu) * keep;
         }
-        split_store(xr[i], buf + d, buf + XUP + d);
+        split_store(xr[i], xs, buf + d, buf + XUP + d, am);
     };
     auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
         if (LC_ABLATE & 1) { asm volatile("" ::"v"(wr[2 * i]), "v"(wr[2 * i + 1])); return; }
@@ -743,11 +768,11 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
                     if constexpr (!EMIT_STATS) {
                         if (pok && co < a.Co) {
-                            const float v = (acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r];
+                            const float v = (acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r];
                             epi_store(&yb[(long long)co * HW + poff], v * a.out_scale);
                         }
                     } else {
-                        const float v = ((acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][j][r]) *
+                        const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
                                         a.out_scale;
                         if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
                         const int m = r >> 2;
@@ -785,395 +810,10 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         }
         h0 += dh; w0 += dw;
     }
+    publish_amax(a.range, am, amax_seen);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Warp-specialised variant of the pipelined kernel.  The PMC profile of conv_f16x2_pipe_kernel
-// (profiles/r01_i_pmc_conv.txt) has the matrix pipe busy 47-56 % of wave lifetime: every wave
-// spends ~45 % of its time staging (loads, hi/lo split, ds_write) or parked, and because all
-// waves run the same code between the same barriers, those phases coincide on a SIMD.  Here the 8
-// waves of a block have two roles.  Waves 0..3 (one per SIMD: a workgroup's waves are dealt to the
-// SIMDs cyclically, so waves k and k+4 share one) only read operand fragments and issue MFMAs;
-// each owns a 64 co x 64 px accumulator tile (4 accumulators, 8 fragment loads per 12 MFMAs
-// instead of 6 per 6).  Waves 4..7 stage the NEXT K chunk -- global loads, fused GroupNorm, hi/lo
-// split, ds_write -- and are parked at the barrier for the rest of the chunk, so the VALU work
-// rides under the other wave's MFMAs.  One barrier per chunk hands the filled buffer over; the
-// producers run ahead across tiles, so a tile's epilogue overlaps the staging of the next tile.
-// STATUS (round 1): parity-tested (tile_cfg 33, never chosen by the heuristic), 0 VGPR spills, but
-// 1.2-1.7x SLOWER than the 8-wave kernel (256->256 @8x8x256: 69.8 vs 57.7 us; 64->64 @8x32x1024:
-// 113 vs 66 us).  Ablation (LC_WS_ABL, 256->256): MFMAs + barriers alone 38 us + 26 us of
-// prologue/epilogue in the first version; one MFMA-issuing wave per SIMD leaves issue gaps that two
-// interleaved waves fill, and the producers' loads are not hidden: VMEM results return in issue
-// order, so consuming the L2-resident weights inside an iteration also waits for the x loads
-// issued before them, and hipcc's s_waitcnt model turns conservative across the loop back-edge
-// (vmcnt(5) where vmcnt(37) is exact).  Two full register sets for weights AND x (104 VGPRs) spill
-// in the producer, and each scratch reload is an s_waitcnt vmcnt(0).  Next step: hand-placed
-// waitcnts around asm loads, or LDS-DMA for the weights with a third weight buffer.
-template <class C, bool EMIT_STATS>
-__global__ __launch_bounds__(2 * C::NT, 2) void conv_f16x2_ws_kernel(ConvArgsH a) {
-    constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
-    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
-    constexpr int KS = 2 * HALO + 1;
-    constexpr int NT = C::NT;                           // threads per ROLE (4 waves)
-    static_assert(NT == 256, "4 consumer + 4 producer waves");
-    constexpr int XUP = XU + 1, WUP = WU + 1;
-    constexpr int BUF = 2 * XUP + 2 * WUP;              // half8 units per LDS buffer
-    __shared__ half8 lds[2 * BUF];
-    __shared__ f32x4 ctab[GN_MAX_C];
-    __shared__ float2 gtab[GN_MAX_G];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave >= NT / 64;              // wave-uniform
-    const int rw = producer ? wave - NT / 64 : wave;    // wave index inside its role
-    const int rtid = tid & (NT - 1);                    // thread index inside its role
-    const int wco = rw / C::WPX_, wpx = rw % C::WPX_;
-
-    const int tpb = a.tpb;
-    int bx = blockIdx.x;
-    if (a.xcd) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
-    int tw_i, th_i;
-    if (a.vert) {
-        const int gh_ = a.tiles_h / tpb;
-        tw_i = bx % a.tiles_w; bx /= a.tiles_w;
-        th_i = (bx % gh_) * tpb; bx /= gh_;
-    } else {
-        const int gw_ = a.tiles_w / tpb;
-        tw_i = (bx % gw_) * tpb; bx /= gw_;
-        th_i = bx % a.tiles_h; bx /= a.tiles_h;
-    }
-    const int b = bx;
-    int h0 = th_i * C::TH_, w0 = tw_i * C::TW_;         // first tile of the block
-    const int dh = a.vert ? C::TH_ : 0, dw = a.vert ? 0 : C::TW_;
-    const int co0 = blockIdx.y * BN;
-    const int H = a.H, W = a.W;
-    const int HW = H * W;
-    const float* xb = a.x + (long long)b * a.x_bs;
-    const int nchunk = a.Cib / CB;
-    const int NG = tpb * nchunk;                        // chunks of the block, over all its tiles
-
-    const bool use_gn = a.gn != nullptr;
-    if (use_gn) {   // rows of the fused input norm of sample b (all 8 waves)
-        if (a.gs.partials) {
-            for (int i = tid; i < a.Cgn; i += 2 * NT) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
-        } else if (a.seg[0].p) {
-            gn_rows_from_ostats<2 * NT>(a, b, tid, ctab, gtab);
-        } else {
-            const f32x4* g = a.gn + (long long)b * a.Cgn;
-            for (int i = tid; i < a.Cgn; i += 2 * NT) ctab[i] = g[i];
-        }
-        __syncthreads();
-    }
-
-    if (producer) {
-        // ================================ producer waves ======================================
-        const unsigned nbytes = (unsigned)a.Ci * (unsigned)HW * 4u;
-        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, nbytes, 0x00020000);
-        unsigned x_voff[NXU];  // byte offset of the unit's first channel in the sample, OOB = pad
-        int x_okmask = 0;      // bit i: unit i of the current LOAD tile is inside the image
-        auto unit_cb = [&](int i) { return (rtid + i * NT) / (XR * XW); };   // constant divisors
-        auto set_tile = [&](int h0t, int w0t) {
-            x_okmask = 0;
-#pragma unroll
-            for (int i = 0; i < NXU; ++i) {
-                const int e = rtid + i * NT;
-                const int cb = e / (XR * XW);
-                const int rem = e - cb * (XR * XW);
-                const int r = rem / XW, c = rem - r * XW;
-                const int gh = h0t - HALO + r;
-                int gw = w0t - HALO + c;
-                gw %= W; if (gw < 0) gw += W;
-                const bool ok = e < XU && gh >= 0 && gh < H;
-                x_voff[i] = ok ? (unsigned)(cb * 8 * HW + gh * W + gw) * 4u : 0xFFFFFFF0u;
-                x_okmask |= ok ? (1 << i) : 0;
-            }
-        };
-        // weights through buffer descriptors: one 32-bit offset per unit instead of two 64-bit
-        // pointers (which hipcc hoists out of the loop and spills -- and every scratch reload is
-        // an s_waitcnt vmcnt(0) on top of the prefetch loads in flight)
-        const unsigned wbytes = (unsigned)(NTAP * a.Cib) * (unsigned)a.Cop * 16u;
-        __amdgpu_buffer_rsrc_t rs_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, wbytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, wbytes, 0x00020000);
-        unsigned w_off[NWU];
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) {
-            int e = rtid + i * NT;
-            if (e >= WU) e = WU - 1;
-            const int row = e / BN, cu = e - row * BN;
-            const int tap = row / CB, cb = row - tap * CB;
-            w_off[i] = (unsigned)((tap * a.Cib + cb) * a.Cop + co0 + cu) * 16u;
-        }
-        const unsigned w_chunk = (unsigned)(CB * a.Cop) * 16u;   // bytes between K chunks
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        // x: two register sets -- while one is split into LDS the other's loads are still in
-        // flight, so every HBM load has two chunk times to land; weights (L2-resident): one set
-        float xrA[NXU][8], xrB[NXU][8];
-        int cb8A = 0, cb8B = 0;                         // in-image mask of the tile a set was loaded from
-        half8 wr[NWU];                                  // ONE weight plane at a time (hi, then lo)
-        auto load_x = [&](float (&xr)[NXU][8], int& okm, int ch) {
-            if (LC_WS_ABL & 2) return;
-            okm = x_okmask;
-#pragma unroll
-            for (int i = 0; i < NXU; ++i) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    xr[i][k] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, x_voff[i],
-                                                                    (unsigned)(ch * 16 + k) * HW * 4u, 0));
-            }
-        };
-        auto load_wp = [&](__amdgpu_buffer_rsrc_t rs, int ch) {
-            if (LC_WS_ABL & 2) return;
-#pragma unroll
-            for (int i = 0; i < NWU; ++i)
-                wr[i] = __builtin_bit_cast(half8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(
-                                                      rs, w_off[i], (unsigned)ch * w_chunk, 0));
-        };
-        auto store_wp = [&](half8* plane) {
-            if (LC_WS_ABL & 4) return;
-#pragma unroll
-            for (int i = 0; i < NWU; ++i) {
-                const int e = rtid + i * NT;
-                plane[e < WU ? e : WU] = wr[i];
-            }
-        };
-        auto load_w = [&](int ch) { load_wp(rs_wh, ch); };     // the hi plane of the NEXT staged chunk
-        // split / copy one chunk (x in `xr`, hi weights in `wr`) into `buf`.  The lo plane is
-        // fetched (L2-resident) and lands while the x units are split: 20 weight registers.
-        auto stage = [&](half8* buf, float (&xr)[NXU][8], int okm, int ch) {
-            store_wp(buf + 2 * XUP);
-            load_wp(rs_wl, ch);
-            if (!(LC_WS_ABL & 4)) {
-#pragma unroll
-                for (int i = 0; i < NXU; ++i) {
-                    const int e = rtid + i * NT;
-                    const int d = e < XU ? e : XU;      // dummy slot for the padding units
-                    if (use_gn) {   // padding units stay exactly 0
-                        const bool in = (okm >> i) & 1;
-                        const f32x4* g = ctab + ch * 16 + (in ? 8 * unit_cb(i) : 0);
-                        const float keep = in ? 1.0f : 0.0f;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu) * keep;
-                    }
-                    split_store(xr[i], buf + d, buf + XUP + d);
-                }
-            }
-            store_wp(buf + 2 * XUP + WUP);
-        };
-        // (tile, chunk) cursor of the x LOADS; advance() moves it to the block's next chunk
-        int l_tile = 0, l_ch = 0;
-        auto advance = [&]() {
-            if (++l_ch == nchunk) {
-                l_ch = 0;
-                if (++l_tile < tpb) set_tile(h0 + l_tile * dh, w0 + l_tile * dw);
-            }
-            return l_tile < tpb;
-        };
-        half8* buf0 = lds;
-        half8* buf1 = lds + BUF;
-        // VMEM results return in issue order and s_waitcnt counts what is still outstanding, so
-        // whatever an iteration needs must be OLDER than the loads that are to stay in flight
-        // across it: per iteration the issue order is  weights(g+2), x(g+3)  and iteration g+1
-        // needs x(g+2) [two iterations old] and weights(g+2) -- never the x loads just issued.
-        // The steady-state loop is branch-free so that hipcc's counter model stays exact.
-        set_tile(h0, w0);
-        int g = 0;
-        int chA = 0, chB = 0;
-        bool haveA = true, haveB = false;
-        load_w(0);
-        load_x(xrA, cb8A, 0);                           // chunk 0 (+ its hi weights)
-        if (NG >= 6) {
-            advance(); chB = l_ch; load_x(xrB, cb8B, chB);          // chunk 1
-            stage(buf0, xrA, cb8A, 0);                  // chunk 0 -> buffer 0
-            load_w(chB);
-            advance(); chA = l_ch; load_x(xrA, cb8A, chA);          // chunk 2
-            __syncthreads();                            // chunk 0 visible to the consumers
-            for (; g + 4 < NG; g += 2) {                // chunks g+3 and g+4 exist
-                stage(buf1, xrB, cb8B, chB);            // chunk g + 1
-                load_w(chA);
-                advance(); chB = l_ch; load_x(xrB, cb8B, chB);      // chunk g + 3
-                __syncthreads();
-                stage(buf0, xrA, cb8A, chA);            // chunk g + 2
-                load_w(chB);
-                advance(); chA = l_ch; load_x(xrA, cb8A, chA);      // chunk g + 4
-                __syncthreads();
-            }
-            haveA = haveB = true;                       // A: chunk g + 2 (in flight), B: chunk g + 1
-        } else {
-            haveB = advance();
-            if (haveB) { chB = l_ch; load_x(xrB, cb8B, chB); }
-            stage(buf0, xrA, cb8A, 0);
-            if (haveB) load_w(chB);
-            haveA = haveB && advance();
-            if (haveA) { chA = l_ch; load_x(xrA, cb8A, chA); }
-            __syncthreads();
-        }
-        // tail (and short blocks): the same schedule with the existence tests
-        for (; g < NG; g += 2) {
-            if (haveB) {                                // set B holds chunk g + 1 -> buffer 1
-                stage(buf1, xrB, cb8B, chB);
-                if (haveA) load_w(chA);
-                haveB = haveA && advance();
-                if (haveB) { chB = l_ch; load_x(xrB, cb8B, chB); }
-            }
-            __syncthreads();
-            if (g + 1 >= NG) break;
-            if (haveA) {                                // set A holds chunk g + 2 -> buffer 0
-                stage(buf0, xrA, cb8A, chA);
-                if (haveB) load_w(chB);
-                haveA = haveB && advance();
-                if (haveA) { chA = l_ch; load_x(xrA, cb8A, chA); }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ==================================== consumer waves ======================================
-    f32x16 acc[C::TCO_][C::TPX_];
-#pragma unroll
-    for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TPX_; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int kh = lane >> 5, l31 = lane & 31;
-    int xbase[C::TPX_];
-#pragma unroll
-    for (int j = 0; j < C::TPX_; ++j) {
-        const int t = wpx * C::TPX_ + j;
-        const int tr = t / C::TPR, tc = t - tr * C::TPR;
-        xbase[j] = kh * (XR * XW) + tr * XW + tc * 32 + l31;
-    }
-    const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
-    auto compute = [&](const half8* cur) {
-        const half8* cxh = cur;
-        const half8* cxl = cur + XUP;
-        const half8* cwh = cur + 2 * XUP;
-        const half8* cwl = cwh + WUP;
-        half8 ah[2][C::TCO_], al[2][C::TCO_], bh[2][C::TPX_], bl[2][C::TPX_];
-        auto fetch = [&](int tap, int s) {
-            const int dy = tap / KS, dx = tap - dy * KS;
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i) {
-                ah[s][i] = cwh[tap * CB * BN + wbase + i * 32];
-                al[s][i] = cwl[tap * CB * BN + wbase + i * 32];
-            }
-#pragma unroll
-            for (int j = 0; j < C::TPX_; ++j) {
-                bh[s][j] = cxh[xbase[j] + dy * XW + dx];
-                bl[s][j] = cxl[xbase[j] + dy * XW + dx];
-            }
-        };
-        if (LC_WS_ABL & 1) return;
-        fetch(0, 0);
-#pragma unroll
-        for (int tap = 0; tap < NTAP; ++tap) {
-            const int s = tap & 1;
-            if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    const int co_wave = co0 + wco * C::TCO_ * 32 + 4 * kh;
-    float bias_r[C::TCO_][16];
-#pragma unroll
-    for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-            bias_r[i][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
-        }
-    float* yb = a.y + (long long)b * a.y_bs;
-    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
-    const half8* cur = lds;
-    const half8* nxt = lds + BUF;
-    __syncthreads();                                    // chunk 0 staged
-    for (int tile = 0; tile < tpb; ++tile) {
-        for (int ch = 0; ch < nchunk; ++ch) {
-            compute(cur);
-            __syncthreads();
-            const half8* t = cur; cur = nxt; nxt = t;
-        }
-        // ---- epilogue of this tile (the producers are already staging the next one) ----------
-        float st_p[C::TCO_][4], st_s[C::TCO_][4], st_q[C::TCO_][4];
-        int nvalid = 0;
-#pragma unroll
-        for (int j = 0; j < C::TPX_; ++j) {
-            const int t = wpx * C::TPX_ + j;
-            const int tr = t / C::TPR, tc = t - tr * C::TPR;
-            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-            const bool pok = gh < H && gw < W;
-            const long long poff = (long long)gh * W + gw;
-            if constexpr (EMIT_STATS) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
-            // all residual loads of this pixel column first: the stores below are asm statements
-            // with a memory clobber, loads placed between them would be serialised
-            float res_r[C::TCO_][16];
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    res_r[i][r] = (rb && pok && co < a.Co) ? rb[(long long)co * HW + poff] : 0.0f;
-                }
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const float v = ((acc[i][j][r] * OUT_UNSCALE + bias_r[i][r]) + res_r[i][r]) * a.out_scale;
-                    if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
-                    if constexpr (EMIT_STATS) {
-                        const int m = r >> 2;
-                        if (j == 0 && (r & 3) == 0) {
-                            st_p[i][m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
-                            st_s[i][m] = 0.f; st_q[i][m] = 0.f;
-                        }
-                        const float d = pok ? v - st_p[i][m] : 0.0f;
-                        st_s[i][m] += d;
-                        st_q[i][m] = fmaf(d, d, st_q[i][m]);
-                    }
-                    acc[i][j][r] = 0.0f;
-                }
-            }
-        }
-        if constexpr (EMIT_STATS) {
-            const int slot = ((h0 / C::TH_) * a.tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
-            const int co_blk = co0 + wco * C::TCO_ * 32;
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int co_oct = co_blk + i * 32 + 8 * m;
-                    const float s_ = wave_sum_to_lane63(st_s[i][m]);
-                    const float q_ = wave_sum_to_lane63(st_q[i][m]);
-                    if (lane == 63 && co_oct < a.Co)
-                        a.ostats[((long long)b * (a.Co >> 3) + (co_oct >> 3)) * a.oslots + slot] =
-                            f32x4{st_p[i][m], (float)(8 * nvalid), s_, q_};
-                }
-            }
-        }
-        h0 += dh; w0 += dw;
-    }
-}
-
-template <class C, bool WS = false>
+template <class C>
 int launch_pipe(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
@@ -1202,13 +842,8 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     dim3 grid(a.B * a.tiles_h * a.tiles_w / tpb, ncot);
     a.xcd = (xcd_env && grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
 
-    if constexpr (WS) {
-        if (a.ostats) hipLaunchKernelGGL((conv_f16x2_ws_kernel<C, true>), grid, dim3(2 * C::NT), 0, st, a);
-        else hipLaunchKernelGGL((conv_f16x2_ws_kernel<C, false>), grid, dim3(2 * C::NT), 0, st, a);
-    } else {
-        if (a.ostats) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
-        else hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
-    }
+    if (a.ostats) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
     return lc_launch_status();
 }
 
@@ -1236,9 +871,6 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 23: return launch_pipe<HCfg<2, 4, 1, 2, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px (1x2)
         case 25: return launch_pipe<HCfg<2, 4, 1, 1, 2, 64, KS>>(a, st);  // 8 waves, 64 co x 128 px
         case 28: return launch_pipe<HCfg<1, 8, 1, 1, 4, 64, KS>>(a, st);  // 8 waves, 32 co x 256 px (Co <= 32)
-        case 33:   // warp-specialised: 4 consumer waves (64 co x 64 px each) + 4 producer waves
-            if constexpr (KS == 3) return launch_pipe<HCfg<1, 4, 2, 2, 4, 64, KS>, true>(a, st);
-            else return LC_EUNSUP;
         default: return LC_EUNSUP;
     }
 }
@@ -1255,7 +887,6 @@ int pipe_stat_slots(int cfg, int H, int W) {
         case 23: th = 4; tw = 64; wpx = 4; break;
         case 25: th = 2; tw = 64; wpx = 4; break;
         case 28: th = 4; tw = 64; wpx = 8; break;
-        case 33: th = 4; tw = 64; wpx = 4; break;
         default: return 0;
     }
     return ((H + th - 1) / th) * ((W + tw - 1) / tw) * wpx;
@@ -1285,9 +916,35 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     return 3;
 }
 
+// max |w| of the tensor -> wmeta[2] (atomicMax on the bit pattern; wmeta zeroed before)
+__global__ void weight_amax_kernel(const float* __restrict__ w, long long n, float* wmeta) {
+    float am = 0.0f;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
+         e += (long long)gridDim.x * blockDim.x)
+        am = fmaxf(am, fabsf(w[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0 && am > 0.0f)
+        atomicMax(reinterpret_cast<unsigned*>(wmeta + 2), __float_as_uint(am));
+}
+
+// the weight pre-scale from max|w| (see lc_pack_conv_weight_f16x2 in the header)
+__device__ __forceinline__ float weight_scale_for(float amax) {
+    if (!(amax > 0.0f) || !(amax < 3.0e38f)) return W_PRESCALE_DEFAULT;
+    const float A = amax * W_PRESCALE_DEFAULT;
+    if (A >= 32.0f && A <= 32768.0f) return W_PRESCALE_DEFAULT;
+    int e;
+    frexpf(amax, &e);                                   // amax = m * 2^e, m in [0.5, 1)
+    int k = 13 - e;
+    k = k < -120 ? -120 : (k > 120 ? 120 : k);
+    return ldexpf(1.0f, k);                             // amax * scale in [2^12, 2^13)
+}
+
 __global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __restrict__ ph,
                                      _Float16* __restrict__ pl, int Co, int Ci, int ntap, int Cib,
-                                     int Cop) {
+                                     int Cop, float* wmeta) {
+    const float ws = weight_scale_for(wmeta[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { wmeta[0] = ws; wmeta[1] = 1.0f / ws; }
     const long long n = (long long)ntap * Cib * Cop * 8;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x) {
@@ -1297,11 +954,11 @@ __global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __re
         const int cb = r % Cib;
         const int tap = r / Cib;
         const int ci = cb * 8 + k;
-        float v = (co < Co && ci < Ci) ? w[((long long)co * Ci + ci) * ntap + tap] * W_PRESCALE : 0.0f;
-        v = fminf(fmaxf(v, -60000.0f), 60000.0f);
-        const _Float16 h = (_Float16)v;
-        ph[e] = h;
-        pl[e] = (_Float16)(v - (float)h);
+        const float v = (co < Co && ci < Ci) ? w[((long long)co * Ci + ci) * ntap + tap] * ws : 0.0f;
+        // the split rule of the activations: hi = 11 significant bits (truncated, exact), lo = rest
+        const float hf = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
+        ph[e] = (_Float16)hf;
+        pl[e] = (_Float16)(v - hf);
     }
 }
 
@@ -1313,13 +970,17 @@ extern "C" int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks) {
 }
 
 extern "C" int lc_pack_conv_weight_f16x2(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci,
-                                         int ks, lc_stream_t s) {
-    if (!w || !wp_hi || !wp_lo || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3)) return LC_EINVAL;
+                                         int ks, float* wmeta, lc_stream_t s) {
+    if (!w || !wp_hi || !wp_lo || !wmeta || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3)) return LC_EINVAL;
     const int Cib = (Ci + 15) / 16 * 2, Cop = (Co + 63) / 64 * 64;
     const long long n = (long long)ks * ks * Cib * Cop * 8;
+    const long long nw = (long long)Co * Ci * ks * ks;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    const int ablocks = (int)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256);
+    if (hipMemsetAsync(wmeta, 0, 4 * sizeof(float), lc_s(s)) != hipSuccess) return lc_launch_status();
+    hipLaunchKernelGGL(weight_amax_kernel, dim3(ablocks), dim3(256), 0, lc_s(s), w, nw, wmeta);
     hipLaunchKernelGGL(pack_weight_h_kernel, dim3(blocks), dim3(256), 0, lc_s(s), w,
-                       (_Float16*)wp_hi, (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop);
+                       (_Float16*)wp_hi, (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop, wmeta);
     return lc_launch_status();
 }
 
@@ -1329,14 +990,16 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
                                         int Co, int H, int W, int ks, float out_scale, int tile_cfg,
                                         const float* gn_coeffs, int gn_cpad, int gn_silu,
                                         const lc_gn_stats_input* gn_stats, float* gn_ostats_out,
-                                        lc_stream_t s) {
-    if (!x || !wp_hi || !wp_lo || !y || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0)
+                                        const float* wmeta, lc_conv_range* range, lc_stream_t s) {
+    if (!x || !wp_hi || !wp_lo || !y || !wmeta || !range || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 ||
+        W <= 0)
         return LC_EINVAL;
     if (ks != 1 && ks != 3) return LC_EUNSUP;
     if ((long long)H * W >= (1 << 24)) return LC_EUNSUP;
     ConvArgsH a;
     a.x = x; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
     a.y = y; a.x_bs = x_bs; a.res_bs = res_bs; a.y_bs = y_bs;
+    a.range = range; a.wmeta = wmeta;
     a.B = B; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W;
     a.Cib = (Ci + 15) / 16 * 2; a.Cop = (Co + 63) / 64 * 64;
     a.out_scale = out_scale;
