@@ -1,14 +1,22 @@
 #!/usr/bin/env python
 """Benchmark of the denoising hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  python bench.py --gpus N --steps K --warmup W [--repeat R]
+  (N>1: one rank per GPU over RCCL -- under `python -m torch.distributed.run --nproc-per-node N`, as
+   the driver launches it, or started plainly, in which case it re-executes itself under
+   torch.distributed.run with N local ranks; --gpus must equal WORLD_SIZE)
 
 A "step" = one reverse-diffusion step of the C2 workload of BASELINE.json (EfficientUNet
 `nuscenes-unet-uncond`, 32x1024 range image, DDIM, batch 8 PER GPU, seeded random-init weights,
 synthetic x_T): one denoiser forward + the fused x0/clamp/update kernel, inputs resident in HBM.
 Weak scaling: every rank owns its own batch of 8 samples (global sample index = rank*8 + i); the
 only communication is one RCCL all-gather of the finished frames after the loop.
+
+Timing: W warmup steps, then R sweeps (default 10) of EXACTLY K steps, each sweep bracketed by a
+barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` and
+`ms_per_step` come from the MEDIAN sweep, `timing` carries all sweeps and the spread (R = 1
+reproduces the single-sweep protocol).  Before timing, one step of the bench configuration is
+checked against the reference's own output (tests/golden/c2_b8.npz, `verify`).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     -- dominant kernel (3x3 ring conv, f16x2-split MFMA): algorithmic FLOPs / HIP-event time
@@ -86,12 +94,46 @@ def cpu_baseline(n_steps: int = 2):
                       f"{dt:.1f} s wall"}
 
 
+def verify_against_reference(ddpm, rank, world, device):
+    """One DDIM step of the BENCH configuration (batch 8, 50-step schedule, x_T from CPU generators
+    seeded with the global sample index -- exactly what the timed loop runs) and the full 50-step
+    run's final frames against the reference's own CPU run (tests/golden/c2_b8.npz, every 4th
+    column).  Rank r checks its own shard when r == 0 (the fixture holds samples 0..7)."""
+    import numpy as np
+
+    path = os.path.join(ROOT, "tests", "golden", "c2_b8.npz")
+    if rank != 0 or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    x_T = x_T_for(0, ddpm.sampling_shape, 1).to(device)
+    st = ddpm.begin_sampling(BATCH_PER_GPU, 50, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
+    out = {}
+    for i in range(1, 51):
+        x = ddpm.sampling_step(st)
+        if i in (1, 25, 50):
+            a = x[..., ::4].double().cpu().flatten(1)
+            b = torch.from_numpy(g[f"x{i}_s4"]).double().flatten(1)
+            out[f"x{i}"] = float(((a - b).norm(dim=1) / b.norm(dim=1)).max())
+    tol = 1e-3
+    ok = all(v < tol for v in out.values())
+    res = {"ok": ok, "tolerance_rel_l2": tol, "max_rel_l2_per_sample": {k: float(f"{v:.3g}") for k, v in out.items()},
+           "against": "tests/golden/c2_b8.npz (the reference's CPU run of C2: batch 8, 50 DDIM steps, "
+                      "same seeds), states 1 / 25 / 50"}
+    if not ok:
+        raise SystemExit(f"bench.py: the bench configuration does not reproduce the reference: {res}")
+    return res
+
+
 def main():
     global BATCH_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeat", type=int, default=10,
+                    help="sweeps of the K timed steps (median reported; 1 = single sweep)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the golden-vector check of the bench configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU,
@@ -102,9 +144,27 @@ def main():
     args = ap.parse_args()
 
     BATCH_PER_GPU = args.batch
+    if args.gpus < 1 or args.repeat < 1 or args.steps < 1:
+        raise SystemExit("bench.py: --gpus, --steps and --repeat must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: become N ranks (one per GPU) under torch.distributed.run
+        import socket
+        import subprocess
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"--nproc-per-node {args.gpus} (or without torchrun: bench.py re-executes "
+                         "itself under torch.distributed.run)")
     # (LC_BENCH_FORCE_DIST=1: take the process-group / barrier / all-gather path with one rank too,
     #  to exercise it on a single-GPU box)
     dist_on = world > 1 or os.environ.get("LC_BENCH_FORCE_DIST") == "1"
@@ -116,6 +176,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
         dist.init_process_group("nccl", device_id=device)
 
     from lidarcrafter_amd import ops as K
@@ -126,10 +190,14 @@ def main():
     # The sampler launches step 0 eagerly and captures its HIP graph at step 1; with fewer than two
     # warmup steps that one-off setup would land in the timed region, so it is run up front (and
     # reported as config.graph_setup_steps) -- the W warmup and K timed steps are all graph replays.
+    verify = None
+    if not args.no_verify and BATCH_PER_GPU == 8:
+        verify = verify_against_reference(ddpm, rank, world, device)
     setup = max(0, 2 - args.warmup)
-    total = setup + args.warmup + args.steps
+    total = setup + args.warmup + args.steps * args.repeat
     x_T = x_T_for(rank, ddpm.sampling_shape, world).to(device)
     st = ddpm.begin_sampling(BATCH_PER_GPU, total, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
+    K.range_poll(device)
     for _ in range(setup):
         ddpm.sampling_step(st)
 
@@ -140,23 +208,32 @@ def main():
 
     for _ in range(args.warmup):
         ddpm.sampling_step(st)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ddpm.sampling_step(st)
-    frames = st["x"]
-    if dist_on:  # reassemble the generated frames once, after the loop (RCCL all-gather)
-        from lidarcrafter_amd import parallel
+    sweeps = []
+    for r in range(args.repeat):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ddpm.sampling_step(st)
+        frames = st["x"]
+        if dist_on and r == args.repeat - 1:
+            # reassemble the generated frames once, after the loop (RCCL all-gather)
+            from lidarcrafter_amd import parallel
 
-        all_frames = parallel.gather_frames(frames, BATCH_PER_GPU * world)
-        assert all_frames.shape[0] == BATCH_PER_GPU * world
-    sync()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+            all_frames = parallel.gather_frames(frames, BATCH_PER_GPU * world)
+            assert all_frames.shape[0] == BATCH_PER_GPU * world
+        sync()
+        dt_r = time.perf_counter() - t0
+        if dist_on:
+            tmax = torch.tensor([dt_r], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_r = float(tmax.item())
+        sweeps.append(dt_r)
+    frames = frames.clone()      # st["x"] is the model's resident buffer; later runs overwrite it
     assert torch.isfinite(frames).all()
+    bad = K.range_poll(device)   # no conv layer of the timed steps ran on saturated fp16 operands
+    assert not bad, f"timed steps are invalid: {bad}"
+    srt = sorted(sweeps)
+    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
 
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -181,7 +258,9 @@ def main():
         split = K.CONV_PRECISION == "f16x2"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         traffic = None   # HBM-side bytes per launch of the dominant kernel, from a separate PMC pass
-        tpath = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
+        tfile = "r02_hbm_traffic.json" if os.path.exists(
+            os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) else "r01_i_hbm_traffic.json"
+        tpath = os.path.join(ROOT, "profiles", tfile)
         if split and BATCH_PER_GPU == 8 and os.path.exists(tpath):
             traffic = round(json.load(open(tpath))["conv3x3_bytes_per_launch"])
         roof = {"bound": "mfma",
@@ -189,8 +268,9 @@ def main():
                           " (all tile instantiations)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_source": ("profiles/r01_i_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 "
-                                   "gfx950 correction) + WRITE_SIZE, separate passes, same workload"
+                "traffic_source": (f"NOT measured in this run: read from profiles/{tfile} (rocprofv3 "
+                                   "--pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate "
+                                   "passes, same workload, devtools/hbm_traffic.py)"
                                    if traffic else None),
                 "note": ("achieved counts ALGORITHMIC flops (2*MACs); the f16x2 split issues 3 "
                          "f16 MFMAs per product, so the attainable ceiling of this kernel is "
@@ -213,6 +293,14 @@ def main():
             "unit": f"denoising-steps/s (each step = batch of {BATCH_PER_GPU} frames per GPU)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "timing": {"protocol": f"{args.repeat} sweeps of exactly {args.steps} steps, each bracketed "
+                                   "by barrier + synchronize, MAX over ranks; value = median sweep",
+                       "repeat": args.repeat, "timed_region_s": round(sum(sweeps), 4),
+                       "sweep_ms_per_step": [round(t / args.steps * 1e3, 4) for t in sweeps],
+                       "min_ms_per_step": round(srt[0] / args.steps * 1e3, 4),
+                       "max_ms_per_step": round(srt[-1] / args.steps * 1e3, 4),
+                       "spread_pct": round((srt[-1] - srt[0]) / dt * 100, 2)},
+            "verify": verify,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f16x2-split MFMA, fp32 accumulate (fp32-class accuracy)"
                       if K.CONV_PRECISION == "f16x2" else "f32"), "data": "synthetic",
@@ -221,7 +309,7 @@ def main():
                                    f"random init), 32x1024, DDIM eta=0, batch {BATCH_PER_GPU} per GPU, "
                                    f"{total}-step schedule (" +
                                    (f"{setup} graph-setup + " if setup else "") +
-                                   f"{args.warmup} warmup + {args.steps} timed)",
+                                   f"{args.warmup} warmup + {args.repeat} x {args.steps} timed)",
                        "graph_setup_steps": setup,
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
                        "resolution": list(RES), "parallelism": f"dp{world} (no data-path collective)",

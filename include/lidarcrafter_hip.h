@@ -247,11 +247,14 @@ int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_t b_bs, flo
  * channel = depth in [min_depth, max_depth] applied by the caller like the reference.
  * points [N,4] (x,y,z,intensity); zbuf u64[H*W] scratch; image [H,W,6]; winner int32[H*W] (-1
  * empty) may be NULL; cells int32[N,2] (grid_h, grid_w) may be NULL.  All float32 operations
- * correctly rounded (asin/atan2 evaluated in fp64, rounded once) -- see oracle/lidar.py "f32".
+ * correctly rounded (asin/atan2 evaluated in fp64, rounded once).  elev_f64 = 1: the elevation ->
+ * row arithmetic runs in float64 on the float32 asin, as the reference computes under numpy >= 2
+ * (oracle/lidar.py "native_cr" -- the mode the committed reference fixtures are reproduced in);
+ * 0: all-float32, the reference under its pinned numpy 1.23.5 (oracle "f32").
  * ------------------------------------------------------------------------------------------- */
 int lc_project_points(const float* points, int N, int H, int W, float fov_up_deg,
                       float fov_down_deg, float min_depth, float max_depth, uint64_t* zbuf,
-                      float* image, int32_t* winner, int32_t* cells, lc_stream_t s);
+                      float* image, int32_t* winner, int32_t* cells, int elev_f64, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Points in rotated boxes: lidargen/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:128-168

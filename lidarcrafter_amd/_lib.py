@@ -34,6 +34,12 @@ class GnStatsInput(C.Structure):
 
 _gs = C.POINTER(GnStatsInput)
 
+
+class ConvRange(C.Structure):
+    """struct lc_conv_range: device-resident pre-scale + running amax of one conv layer's input."""
+    _fields_ = [("x_scale", f32), ("x_unscale", f32), ("amax_scaled", f32), ("reserved", f32)]
+
+
 # name -> (restype, argtypes); mirrors include/lidarcrafter_hip.h one to one
 SIGNATURES = {
     "lc_abi_version": (i32, []),
@@ -43,9 +49,9 @@ SIGNATURES = {
     "lc_conv2d_ring_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32,
                                  f32, i32, vp]),
     "lc_packed_conv_weight_f16x2_elems": (i64, [i32, i32, i32]),
-    "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "lc_conv2d_ring_f16x2_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
-                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp, vp]),
+                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp, vp, vp, vp]),
     "lc_conv2d_ring_f16x2_stats_slots": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "lc_groupnorm_coeffs": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, f32, vp]),
@@ -65,7 +71,7 @@ SIGNATURES = {
     "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),
     "lc_add_scale": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, f32, vp]),
-    "lc_project_points": (i32, [vp, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
+    "lc_project_points": (i32, [vp, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp]),
     "lc_range_postprocess": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "lc_condition_preprocess": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, f32, vp]),
     "lc_layout_scratch_bytes": (i64, [i32, i32]),

@@ -7,15 +7,28 @@ namespace {
 #pragma clang fp contract(off)
 
 // lidargen/dataset/transforms_3d/common.py:44-45,72-81 -- every float32 op correctly rounded
-// (asin/atan2 in fp64, rounded once), matching oracle/lidar.py project_cells(mode="f32").
-__device__ __forceinline__ void cell_of(float x, float y, float z, int H, int W, float h_up,
-                                        float h_down, float& depth, int& gh, int& gw) {
+// (asin/atan2 in fp64, rounded once).  ELEV64 = true: the elevation -> row arithmetic runs in
+// float64 on the float32 asin result, as the reference does under numpy >= 2 (np.deg2rad of a
+// python float is a float64 scalar and promotes the expression; oracle/lidar.py "native_cr");
+// false: all-float32, the reference under its pinned numpy 1.23.5 (oracle "f32").
+template <bool ELEV64>
+__device__ __forceinline__ void cell_of(float x, float y, float z, int H, int W, double h_up64,
+                                        double h_down64, float& depth, int& gh, int& gw) {
     depth = sqrtf((x * x + y * y) + z * z);
     const float t = z / (depth + 1e-6f);
-    const float elev = (float)asin((double)t) + fabsf(h_down);
-    float fh = 1.0f - elev / (h_up - h_down);
-    fh = floorf(fh * (float)H);
-    gh = (int)fminf(fmaxf(fh, 0.f), (float)(H - 1));
+    const float a32 = (float)asin((double)t);
+    if constexpr (ELEV64) {
+        const double elev = (double)a32 + fabs(h_down64);
+        double fh = 1.0 - elev / (h_up64 - h_down64);
+        fh = floor(fh * (double)H);
+        gh = (int)fmin(fmax(fh, 0.0), (double)(H - 1));
+    } else {
+        const float h_up = (float)h_up64, h_down = (float)h_down64;
+        const float elev = a32 + fabsf(h_down);
+        float fh = 1.0f - elev / (h_up - h_down);
+        fh = floorf(fh * (float)H);
+        gh = (int)fminf(fmaxf(fh, 0.f), (float)(H - 1));
+    }
     const float az = -(float)atan2((double)y, (double)x);
     float fw = (az / 3.14159274101257324f + 1.0f) / 2.0f;
     fw = fw - floorf(fw);              // np.mod(v, 1) for v in [0, 1]
@@ -28,16 +41,17 @@ __global__ void zbuf_clear_kernel(unsigned long long* zb, int n) {
     if (i < n) zb[i] = ~0ull;
 }
 
+template <bool ELEV64>
 __global__ __launch_bounds__(256) void project_scatter_kernel(const float* __restrict__ pts, int N,
-                                                             int H, int W, float h_up,
-                                                             float h_down,
+                                                             int H, int W, double h_up,
+                                                             double h_down,
                                                              unsigned long long* __restrict__ zb,
                                                              int* __restrict__ cells) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const f32x4 p = *reinterpret_cast<const f32x4*>(pts + 4ll * i);
     float depth; int gh, gw;
-    cell_of(p.x, p.y, p.z, H, W, h_up, h_down, depth, gh, gw);
+    cell_of<ELEV64>(p.x, p.y, p.z, H, W, h_up, h_down, depth, gh, gw);
     if (cells) { cells[2 * i] = gh; cells[2 * i + 1] = gw; }
     if (depth != depth) return;  // NaN never wins (numpy argsort puts NaN last -> overwritten)
     const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)i;
@@ -133,18 +147,23 @@ __global__ __launch_bounds__(256) void pib_index_kernel(const float* __restrict_
 extern "C" int lc_project_points(const float* points, int N, int H, int W, float fov_up_deg,
                                  float fov_down_deg, float min_depth, float max_depth,
                                  uint64_t* zbuf, float* image, int32_t* winner, int32_t* cells,
-                                 lc_stream_t s) {
+                                 int elev_f64, lc_stream_t s) {
     if ((!points && N > 0) || !zbuf || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
     if (reinterpret_cast<uintptr_t>(points) & 15) return LC_EINVAL;
     const int HW = H * W;
-    // np.deg2rad in float64 then rounded to float32 (oracle/lidar.py mode="f32")
-    const float h_up = (float)((double)fov_up_deg * 0.017453292519943295);
-    const float h_down = (float)((double)fov_down_deg * 0.017453292519943295);
+    // np.deg2rad in float64 (rounded to float32 inside the kernel for the all-float32 mode)
+    const double h_up = (double)fov_up_deg * 0.017453292519943295;
+    const double h_down = (double)fov_down_deg * 0.017453292519943295;
     auto zb = reinterpret_cast<unsigned long long*>(zbuf);
     hipLaunchKernelGGL(zbuf_clear_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), zb, HW);
-    if (N > 0)
-        hipLaunchKernelGGL(project_scatter_kernel, dim3((N + 255) / 256), dim3(256), 0, lc_s(s),
-                           points, N, H, W, h_up, h_down, zb, cells);
+    if (N > 0) {
+        if (elev_f64)
+            hipLaunchKernelGGL(project_scatter_kernel<true>, dim3((N + 255) / 256), dim3(256), 0,
+                               lc_s(s), points, N, H, W, h_up, h_down, zb, cells);
+        else
+            hipLaunchKernelGGL(project_scatter_kernel<false>, dim3((N + 255) / 256), dim3(256), 0,
+                               lc_s(s), points, N, H, W, h_up, h_down, zb, cells);
+    }
     hipLaunchKernelGGL(project_gather_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
                        HW, zb, min_depth, max_depth, image, winner);
     return lc_launch_status();

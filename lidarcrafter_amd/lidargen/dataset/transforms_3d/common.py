@@ -22,8 +22,9 @@ def load_points_as_images(point_path: str = None, points=None, scan_unfolding: b
                           custom_feat_dim: int = 0):
     """-> float32 [H, W, 6] = (x, y, z, intensity, depth, mask).  numpy in -> numpy out, CUDA
     tensor in -> CUDA tensor out (no host round trip).
-    All-float32 semantics of the reference's pinned numpy; equal-depth ties go to
-    the lowest point index."""
+    Elevation -> row arithmetic in float64 like the reference under numpy >= 2 (ops.PROJECTION_DTYPE
+    = "native"; "f32" = its pinned numpy 1.23.5); equal-depth ties go to the lowest
+    point index."""
     assert point_path is not None or points is not None, "Either point_path or points must be provided."
     if scan_unfolding:
         raise NotImplementedError("scan_unfolding=True (KITTI ring unfolding) is not used by any "

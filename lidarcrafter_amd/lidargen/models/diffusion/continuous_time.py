@@ -31,8 +31,12 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     use_hip_graph = os.environ.get("LC_HIP_GRAPH", "1") != "0"
 
     # The reference draws randn_like() in p_step even for DDIM eta=0 where it is multiplied by 0
-    # (continuous_time.py:229).  Set True to also advance the generators in that case.
-    advance_rng_when_unused = False
+    # (continuous_time.py:229).  With EXPLICIT generators the draw is made here too (on the
+    # generator's own device, result discarded, nothing uploaded), so that a generator shared by
+    # several sample() calls -- generate_sequence passes one `rng` to every frame -- ends in the
+    # state a seeded reference run leaves it in.  rng=None (the process-global generator, whose
+    # stream differs between CPU and GPU anyway) is not advanced.  False skips the draw always.
+    advance_rng_when_unused = True
 
     def __init__(self, model: nn.Module, condition_model: nn.Module = None,
                  prediction_type: Literal["eps", "v", "x_0"] = "eps", loss_type="l2",
@@ -108,8 +112,11 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     def _noise_for(self, x_t, rng, mode, ddim_eta):
         if mode == "ddpm" or ddim_eta != 0.0:
             return self.randn_like(x_t, rng=rng)
-        if self.advance_rng_when_unused:
-            self.randn_like(x_t, rng=rng)
+        if self.advance_rng_when_unused and rng is not None:
+            gens = [rng] if isinstance(rng, torch.Generator) else rng
+            shape = x_t.shape if isinstance(rng, torch.Generator) else x_t.shape[1:]
+            for g in gens:
+                torch.randn(*shape, generator=g, device=g.device, dtype=x_t.dtype)
         return None
 
     def _predict(self, x_t, log_snr_t, time_features=None):
@@ -117,6 +124,7 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
             return self.model(x_t, log_snr_t, time_features=time_features)
         return self.model(x_t, log_snr_t)
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def p_step(self, x_t, step_t, step_s, rng=None, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
@@ -155,6 +163,7 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         return x.clone()
 
     # ---- the sampling loop, exposed step-wise (bench.py times exactly K calls of `sampling_step`)
+    @torch.compiler.disable
     @torch.inference_mode()
     def begin_sampling(self, batch_size: int, num_steps: int, rng=None,
                        mode: Literal["ddpm", "ddim"] = "ddpm", ddim_eta: float = 0.0, x_T=None,
@@ -217,9 +226,14 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         g["graph"] = graph
         return g
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def sampling_step(self, st: dict) -> torch.Tensor:
         """One reverse step: denoiser forward + fused x0/clamp/update, in place on the resident x."""
+        with K.defer_range_checks():     # callers of the step-wise API poll (ops.range_poll) themselves
+            return self._sampling_step(st)
+
+    def _sampling_step(self, st: dict) -> torch.Tensor:
         i, B, x = st["i"], st["B"], st["x"]
         tf = None if st["tf"] is None else tuple(a[i * B:(i + 1) * B] for a in st["tf"])
         noise = self._noise_for(x, st["rng"], st["mode"], st["eta"])
@@ -247,18 +261,25 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         st["i"] = i + 1
         return x
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_size: int, num_steps: int, progress: bool = True, rng=None,
                return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
-        st = self.begin_sampling(batch_size, num_steps, rng, mode, ddim_eta)
-        out = [st["x_T"]] if return_all else None
-        for _ in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-            x = self.sampling_step(st)
-            if return_all:
-                out.append(x.clone())
-        return torch.stack(out) if return_all else st["x"].clone()
+        def run():
+            st = self.begin_sampling(batch_size, num_steps, rng, mode, ddim_eta)
+            out = [st["x_T"]] if return_all else None
+            for _ in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+                x = self.sampling_step(st)
+                if return_all:
+                    out.append(x.clone())
+            return torch.stack(out) if return_all else st["x"].clone()
 
+        # the conv range records are polled ONCE, after the loop; a run in which a layer's fp16
+        # operands saturated is repeated with the same draws (ops.run_range_safe)
+        return K.run_range_safe(run, rng, self.device, "ContinuousTimeGaussianDiffusion.sample")
+
+    @torch.compiler.disable
     @torch.inference_mode()
     def repaint(self, known, mask, num_steps, num_resample_steps: int = 1, jump_length: int = 1,
                 progress: bool = True, rng=None, return_all: bool = False):

@@ -40,6 +40,7 @@ class CondContinuousTimeGaussianDiffusion(continuous_time.ContinuousTimeGaussian
             return self.model(torch.cat([x_t, other], dim=1), td, **kw)
         return self.model(x_t, condition_dict, **kw)
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def p_step(self, x_t, condition_dict: dict, step_t, step_s, rng=None,
                mode: Literal["ddpm", "ddim"] = "ddpm", ddim_eta: float = 0.0):
@@ -54,22 +55,27 @@ class CondContinuousTimeGaussianDiffusion(continuous_time.ContinuousTimeGaussian
         return K.pstep(x_t, pred, noise, coef.to(x_t.device), self._objective_id(),
                        schedules.MODES[mode])
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_dict: dict, batch_size: int, num_steps: int, progress: bool = True,
                rng=None, return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",
                ddim_eta: float = 0.0):
-        x_T = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
-        condition_dict = self.get_network_condition(input_dict=batch_dict,
-                                                    only_custom_condition=True)
-        st = self.begin_sampling(batch_size, num_steps, rng, mode, ddim_eta, x_T=x_T,
-                                 condition_dict=condition_dict)
-        out = [st["x_T"]] if return_all else None
-        for _ in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
-            x = self.sampling_step(st)
-            if return_all:
-                out.append(x.clone())
-        return torch.stack(out) if return_all else st["x"].clone()
+        def run():
+            x_T = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
+            condition_dict = self.get_network_condition(input_dict=batch_dict,
+                                                        only_custom_condition=True)
+            st = self.begin_sampling(batch_size, num_steps, rng, mode, ddim_eta, x_T=x_T,
+                                     condition_dict=condition_dict)
+            out = [st["x_T"]] if return_all else None
+            for _ in tqdm(range(num_steps), desc="sampling", leave=False, disable=not progress):
+                x = self.sampling_step(st)
+                if return_all:
+                    out.append(x.clone())
+            return torch.stack(out) if return_all else st["x"].clone()
 
+        return K.run_range_safe(run, rng, self.device, "CondContinuousTimeGaussianDiffusion.sample")
+
+    @torch.compiler.disable
     @torch.inference_mode()
     def inpaint(self, known, mask, batch_dict: dict, num_steps: int, num_resample_steps: int = 1,
                 jump_length: int = 1, progress: bool = True, rng=None, return_all: bool = False):

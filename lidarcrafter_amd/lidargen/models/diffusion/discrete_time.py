@@ -58,6 +58,7 @@ class DiscreteTimeGaussianDiffusion(base.GaussianDiffusion):
         ab = self.alpha_bar[steps]
         return ab.sqrt() * x_0 + (1 - ab).sqrt() * noise, noise
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def p_step(self, x_t, steps, rng=None, mode: Literal["ddpm", "ddim"] = "ddim", eta: float = 0.0):
         beta, ab, abp = self.beta[steps], self.alpha_bar[steps], self.alpha_bar_prev[steps]
@@ -91,6 +92,7 @@ class DiscreteTimeGaussianDiffusion(base.GaussianDiffusion):
             return x_s
         raise ValueError(f"invalid mode {mode}")
 
+    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_size, num_steps, progress=True, rng=None, return_all=False,
                mode: Literal["ddpm", "ddim"] = "ddpm"):

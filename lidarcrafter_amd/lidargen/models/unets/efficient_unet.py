@@ -211,6 +211,7 @@ class EfficientUNet(nn.Module):
         self._C = C
         self._ada_cache = None
         self._in_buf = None
+        K.name_packed_convs(self)
 
     # ---- step-invariant / batched helpers ------------------------------------------------------
     _BLOCKS = ("d_block1", "d_block2", "d_block3", "d_block4",
@@ -267,9 +268,13 @@ class EfficientUNet(nn.Module):
             self._in_buf = (key, buf)
         return self._in_buf[1]
 
+    @torch.compiler.disable
+    @K.range_checked
     def forward(self, images: torch.Tensor, timesteps: torch.Tensor, time_features=None):
         """images [B, C, H, W], timesteps = log-SNR [B] (or 0-d) -> prediction [B, C_out, H, W].
-        `time_features`: optional precomputed `self.time_features(log_snr)` (sampler hoists it)."""
+        `time_features`: optional precomputed `self.time_features(log_snr)` (sampler hoists it).
+        Range-checked: a standalone call polls the conv range records afterwards and recomputes if
+        a layer's fp16 operands saturated (ops.range_checked); samplers defer that to the run's end."""
         B, _, H, W = images.shape
         if time_features is None:
             if timesteps.dim() == 0:

@@ -278,6 +278,7 @@ class LayoutUnetV1(nn.Module):
         self.use_fp16 = use_fp16
         self._emb_cache = None
         self._in_buf = None
+        K.name_packed_convs(self)
 
     # ---- batched / step-invariant helpers -------------------------------------------------------
     def _res_blocks(self):
@@ -336,6 +337,8 @@ class LayoutUnetV1(nn.Module):
                     m._cond_cache = None      # never trust a cache across conditions
                     m.condition_operands(layout_outputs)
 
+    @torch.compiler.disable
+    @K.range_checked
     def forward(self, x, cond_dict, time_features=None):
         lay = cond_dict["other_condition"]
         B, cx, H, W = x.shape

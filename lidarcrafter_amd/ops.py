@@ -14,9 +14,12 @@ import torch
 from ._lib import check, lib
 
 _F32 = torch.float32
+_HALF = (torch.float16, torch.bfloat16)
 
 
 def _stream() -> int:
+    # the current stream of the CURRENT device: every public op runs under `_entry`, which makes
+    # the device of its tensors current for the duration of the call
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -25,7 +28,51 @@ def _req(t: torch.Tensor, name: str) -> None:
         raise RuntimeError(f"lidarcrafter_amd.ops: `{name}` must be a CUDA(HIP) tensor -- the hot "
                            "path has no CPU fallback (oracle/ holds the CPU restatement for tests)")
     if t.dtype != _F32:
-        raise TypeError(f"`{name}` must be float32, got {t.dtype}")
+        raise TypeError(f"`{name}` must be float32, got {t.dtype} (float16 / bfloat16 INPUTS are "
+                        "up-cast at the op boundary, e.g. under torch.autocast; `out=` tensors and "
+                        "other dtypes are not)")
+
+
+def _entry(fn):
+    """Boundary of every public op:
+      * device: the kernels are launched on the current stream of the device the tensors live on
+        (the reference's modules work on any device index); when that is not the current device it
+        is made current for the call (torch.cuda.device), so `setup_model(device='cuda:1')` works
+        without torch.cuda.set_device;
+      * dtype: the kernels compute in fp32.  float16 / bfloat16 CUDA tensor inputs -- what
+        torch.autocast makes of the layout encoder's nn.Linear outputs in the reference's bulk
+        harness (tools/evaluation/sample_and_save_cond.py:64,145) -- are up-cast here; the result is
+        float32 (an `out=` tensor must be float32)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        dev = None
+        cast = False
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                if a.dtype in _HALF:
+                    cast = True
+        for k, a in kw.items():
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                if a.dtype in _HALF and k != "out":
+                    cast = True
+        if cast:
+            args = tuple(a.float() if isinstance(a, torch.Tensor) and a.is_cuda and a.dtype in _HALF
+                         else a for a in args)
+            kw = {k: (a.float() if isinstance(a, torch.Tensor) and a.is_cuda and a.dtype in _HALF
+                      and k != "out" else a) for k, a in kw.items()}
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+
+    wrapper._lc_entry = True
+    return wrapper
 
 
 def _bs4(t: torch.Tensor, name: str) -> int:
@@ -187,17 +234,269 @@ def _find_stats(x: torch.Tensor, G: int):
     return None
 
 
+# ------------------------------------------------------------------------------------ range safety
+# The f16x2 kernels multiply every conv input by a per-layer power of two (x_scale, default 16)
+# before the fp16 hi/lo split; fp16 saturates at 65504.  Each layer owns a 16-byte `lc_conv_range`
+# record in device memory (one arena per device, so a poll is ONE device->host copy): the kernels
+# read x_scale from it and atomically publish max |x * x_scale| of everything they staged.
+#   range_poll(device)  reads all records (synchronises), resets the maxima and re-derives x_scale
+#                       of every layer whose scaled maximum left the safe window; it returns the
+#                       layers whose results since the last poll are INVALID (operands saturated,
+#                       or so small that the lo halves were lost) -- the caller must recompute.
+# The model forwards (`range_checked`) and the samplers poll after each run and recompute until
+# clean: a result computed from clipped operands is never returned.  Inside a sampling loop /
+# graph capture the check is deferred to the end of the run (`defer_range_checks`).
+RANGE_SLOTS = 4096
+X_SCALE_DEFAULT = 16.0
+_A_TARGET_LOG2 = 12            # recalibration puts max|x| * x_scale into [2^12, 2^13)
+_A_INVALID_HI = 65504.0 * (1.0 - 2.0 ** -11)   # hi half saturates
+_A_RECAL_HI = 2.0 ** 15        # within 2x of saturation: move the scale (results still exact)
+_A_INVALID_LO = 2.0 ** -3      # error relative to max|x| exceeds the split's own 2^-22
+_A_RECAL_LO = 2.0 ** 2
+_range_arenas = {}
+_range_defer = 0
+
+
+class ConvRangeError(ArithmeticError):
+    """The f16x2 convolution could not find a pre-scale under which its input fits fp16 (e.g. inf /
+    NaN activations).  Use LC_CONV_PRECISION=f32 (exact fp32 MFMA kernel) for this model."""
+
+
+class _RangeArena:
+    def __init__(self, device):
+        self.device = device
+        init = torch.zeros((RANGE_SLOTS, 4), dtype=_F32)
+        init[:, 0], init[:, 1] = X_SCALE_DEFAULT, 1.0 / X_SCALE_DEFAULT
+        self.buf = init.to(device)
+        self.scale = [X_SCALE_DEFAULT] * RANGE_SLOTS      # host mirror of x_scale
+        self.free = list(range(RANGE_SLOTS - 1, -1, -1))
+        self.owner = {}                                    # slot -> weakref to the owning PackedConv
+        self.host = torch.empty((RANGE_SLOTS, 4), dtype=_F32).pin_memory() if device.type == "cuda" \
+            else torch.empty((RANGE_SLOTS, 4), dtype=_F32)
+
+    def alloc(self, owner) -> int:
+        import weakref
+
+        if not self.free:
+            raise RuntimeError("range arena exhausted (more than 4096 live conv layers)")
+        slot = self.free.pop()
+        self.owner[slot] = weakref.ref(owner)
+        return slot
+
+    def release(self, slot: int) -> None:
+        self.owner.pop(slot, None)
+        if self.scale[slot] != X_SCALE_DEFAULT:
+            self._set_scale(slot, X_SCALE_DEFAULT)
+        self.free.append(slot)
+
+    def _set_scale(self, slot: int, scale: float) -> None:
+        self.scale[slot] = scale
+        self.buf[slot, :2] = torch.tensor([scale, 1.0 / scale], dtype=_F32)
+
+    def ptr(self, slot: int) -> int:
+        return self.buf.data_ptr() + 16 * slot
+
+
+def _norm_dev(device) -> torch.device:
+    device = torch.device("cuda") if device is None else torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def _arena(device) -> _RangeArena:
+    device = _norm_dev(device)
+    a = _range_arenas.get(device)
+    if a is None:
+        a = _range_arenas[device] = _RangeArena(device)
+    return a
+
+
+class RangeEvent:
+    __slots__ = ("layer", "amax", "old_scale", "new_scale", "invalid")
+
+    def __init__(self, layer, amax, old_scale, new_scale, invalid):
+        self.layer, self.amax, self.old_scale, self.new_scale, self.invalid = \
+            layer, amax, old_scale, new_scale, invalid
+
+    def __repr__(self):
+        return (f"RangeEvent({self.layer!r}: max|x|={self.amax:.4g}, x_scale {self.old_scale:g} -> "
+                f"{self.new_scale:g}, {'INVALID' if self.invalid else 'recalibrated'})")
+
+
+def _scale_for(amax: float) -> float:
+    import math
+
+    if not (amax > 0.0) or not math.isfinite(amax):
+        return X_SCALE_DEFAULT
+    m, e = math.frexp(amax)                 # amax = m * 2^e, m in [0.5, 1)
+    k = max(-100, min(100, _A_TARGET_LOG2 + 1 - e))
+    return math.ldexp(1.0, k)               # amax * scale in [2^12, 2^13)
+
+
+def range_poll(device=None, quiet: bool = True):
+    """Read the range records of every f16x2 conv layer on `device` (one device->host copy; this
+    SYNCHRONISES the current stream), reset the running maxima and move the pre-scale of every layer
+    whose scaled maximum left the safe window.  Returns the list of RangeEvents with
+    `invalid=True` -- layers whose outputs since the previous poll were computed from saturated
+    (or vanishing) fp16 operands and must be recomputed; [] means everything handed out is good."""
+    import math
+    import warnings
+
+    if not torch.cuda.is_available():
+        return []
+    a = _range_arenas.get(_norm_dev(device))
+    if a is None or not a.owner:
+        return []
+    with torch.cuda.device(a.device):
+        a.host.copy_(a.buf, non_blocking=False)
+        a.buf[:, 2].zero_()
+    am = a.host[:, 2]
+    bad = []
+    hot = torch.nonzero((am >= _A_RECAL_HI) | ((am > 0) & (am < _A_RECAL_LO)) | ~torch.isfinite(am))
+    for slot in hot.flatten().tolist():
+        ref = a.owner.get(slot)
+        owner = ref() if ref is not None else None
+        if owner is None:
+            continue
+        A = float(am[slot])
+        old = a.scale[slot]
+        amax = A / old if math.isfinite(A) else float("inf")
+        invalid = (not math.isfinite(A)) or A >= _A_INVALID_HI or A < _A_INVALID_LO
+        new = _scale_for(amax)
+        if new != old:
+            with torch.cuda.device(a.device):
+                a._set_scale(slot, new)
+        ev = RangeEvent(owner.name or f"conv#{slot}", amax, old, new, invalid)
+        if invalid:
+            bad.append(ev)
+        if not quiet or invalid:
+            warnings.warn(f"lidarcrafter_amd f16x2 conv range: {ev}", RuntimeWarning, stacklevel=2)
+    return bad
+
+
+def name_packed_convs(model) -> None:
+    """Give every PackedConv below `model` its module path (range events name the layer)."""
+    for mname, m in model.named_modules():
+        for attr, v in vars(m).items():
+            if isinstance(v, PackedConv) and not v.name:
+                v.name = f"{mname}.{attr.lstrip('_')}" if mname else attr.lstrip("_")
+
+
+def rng_snapshot(rng, device):
+    """State of what `GaussianDiffusion.randn` would draw from (None / Generator / list)."""
+    if rng is None:
+        dev = _norm_dev(device) if torch.device(device).type == "cuda" else None
+        return ("global", torch.get_rng_state(),
+                torch.cuda.get_rng_state(dev) if dev is not None else None, dev)
+    if isinstance(rng, torch.Generator):
+        return ("one", rng.get_state())
+    return ("list", [g.get_state() for g in rng])
+
+
+def rng_restore(rng, snap) -> None:
+    if snap[0] == "global":
+        torch.set_rng_state(snap[1])
+        if snap[2] is not None:
+            torch.cuda.set_rng_state(snap[2], snap[3])
+    elif snap[0] == "one":
+        rng.set_state(snap[1])
+    else:
+        for g, st in zip(rng, snap[1]):
+            g.set_state(st)
+
+
+def run_range_safe(run, rng, device, what: str = "sampling run"):
+    """`run()` under deferred range checks; poll afterwards; if a layer computed from saturated
+    operands, its pre-scale has been moved: restore the generators and run again (bit-identical
+    draws), so the caller never sees a clipped trajectory."""
+    if CONV_PRECISION != "f16x2" or torch.device(device).type != "cuda":
+        return run()
+    range_poll(device)                        # forget what earlier, unrelated work left behind
+    bad = None
+    for _ in range(5):
+        snap = rng_snapshot(rng, device)
+        with defer_range_checks():
+            out = run()
+        bad = range_poll(device)
+        if not bad:
+            return out
+        rng_restore(rng, snap)
+    raise ConvRangeError(f"{what}: f16x2 conv pre-scales did not converge: {bad}")
+
+
+class defer_range_checks:
+    """Context: model forwards inside do not poll (sampling loops / graph capture poll once at the
+    end of the run instead)."""
+
+    def __enter__(self):
+        global _range_defer
+        _range_defer += 1
+
+    def __exit__(self, *exc):
+        global _range_defer
+        _range_defer -= 1
+        return False
+
+
+def range_checked(forward):
+    """Decorator of a denoiser's `forward`: run, poll the conv range records, recompute while any
+    layer reports saturated operands (its pre-scale has been moved by the poll).  No-op for the
+    exact fp32 kernels, inside `defer_range_checks()` and during stream capture."""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapper(self, *args, **kw):
+        x = args[0] if args else None
+        if _range_defer > 0 or CONV_PRECISION != "f16x2" or not isinstance(x, torch.Tensor) or \
+                not x.is_cuda or torch.cuda.is_current_stream_capturing():
+            return forward(self, *args, **kw)
+        for _ in range(5):
+            out = forward(self, *args, **kw)
+            bad = range_poll(x.device)
+            if not bad:
+                return out
+        raise ConvRangeError(f"f16x2 conv pre-scales did not converge: {bad}")
+
+    return wrapper
+
+
 class PackedConv:
     """Packed copies of an OIHW conv weight for the MFMA kernels (fp32 wp[tap][Ci^8][Co^64] and/or
-    the f16x2 hi/lo planes), rebuilt when the parameter changes."""
+    the f16x2 hi/lo planes + their device-derived pre-scale), rebuilt when the parameter changes;
+    also owns the layer's input range record (lc_conv_range) in the device's arena."""
 
-    __slots__ = ("wp", "wh", "wl", "Co", "Ci", "ks", "_key", "_w4")
+    __slots__ = ("wp", "wh", "wl", "wmeta", "Co", "Ci", "ks", "_key", "_w4", "name", "_slot",
+                 "_arena", "__weakref__")
 
-    def __init__(self):
-        self.wp = self.wh = self.wl = None
+    def __init__(self, name: str = ""):
+        self.wp = self.wh = self.wl = self.wmeta = None
         self._key = None
+        self.name = name
+        self._slot = self._arena = None
+
+    def range_ptr(self, device) -> int:
+        if self._arena is None or self._arena.device != device:
+            if self._arena is not None:
+                self._arena.release(self._slot)
+            self._arena = _arena(device)
+            self._slot = self._arena.alloc(self)
+        return self._arena.ptr(self._slot)
+
+    @property
+    def x_scale(self) -> float:
+        return X_SCALE_DEFAULT if self._arena is None else self._arena.scale[self._slot]
+
+    def __del__(self):
+        try:
+            if self._arena is not None:
+                self._arena.release(self._slot)
+        except Exception:
+            pass
 
     def _refresh(self, weight: torch.Tensor):
+        if isinstance(weight, torch.Tensor) and weight.dtype in _HALF:
+            weight = weight.float()
         _req(weight, "weight")
         key = (weight.data_ptr(), weight._version, tuple(weight.shape))
         if key != self._key:
@@ -226,9 +525,11 @@ class PackedConv:
             n = lib().lc_packed_conv_weight_f16x2_elems(self.Co, self.Ci, self.ks)
             self.wh = torch.empty(n, device=weight.device, dtype=torch.float16)
             self.wl = torch.empty(n, device=weight.device, dtype=torch.float16)
+            self.wmeta = torch.empty(4, device=weight.device, dtype=_F32)
             check(lib().lc_pack_conv_weight_f16x2(self._w4.data_ptr(), self.wh.data_ptr(),
                                                   self.wl.data_ptr(), self.Co, self.Ci, self.ks,
-                                                  _stream()), "lc_pack_conv_weight_f16x2")
+                                                  self.wmeta.data_ptr(), _stream()),
+                  "lc_pack_conv_weight_f16x2")
         return self.wh, self.wl
 
 
@@ -297,7 +598,8 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                                                  _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                  Ci, Co, H, W, ks, float(out_scale),
                                                  int(tile_cfg), _p(gn_coeffs), cpad, int(gn_silu),
-                                                 gs_ref, _p(sbuf), _stream()),
+                                                 gs_ref, _p(sbuf), packed.wmeta.data_ptr(),
+                                                 packed.range_ptr(x.device), _stream()),
                   "lc_conv2d_ring_f16x2_fwd")
             if sbuf is not None:
                 _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H, W)))
@@ -584,9 +886,20 @@ def add_scale(a: torch.Tensor, b: torch.Tensor, scale: float, out=None) -> torch
 
 
 # ------------------------------------------------------------------------------------ geometry
+# Arithmetic of the elevation -> image row step: "native" = float64 on the float32 asin, what the
+# reference computes under numpy >= 2 (and what the committed reference fixtures hold); "f32" = the
+# all-float32 flow of the reference's pinned numpy 1.23.5 (environment.yml:233).
+PROJECTION_DTYPE = _os.environ.get("LC_PROJECTION_DTYPE", "native")
+
+
 def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down: float,
-                   min_depth: float, max_depth: float, return_cells: bool = False):
-    """[N,4] (x,y,z,intensity) -> image [H,W,6], winner int32 [H,W] (+ cells int32 [N,2])."""
+                   min_depth: float, max_depth: float, return_cells: bool = False,
+                   dtype_mode: Optional[str] = None):
+    """[N,4] (x,y,z,intensity) -> image [H,W,6], winner int32 [H,W] (+ cells int32 [N,2]).
+    dtype_mode: "native" (default) | "f32", see PROJECTION_DTYPE."""
+    mode = dtype_mode or PROJECTION_DTYPE
+    if mode not in ("native", "f32"):
+        raise ValueError(f"projection dtype mode {mode!r}")
     _req(points, "points")
     if points.dim() != 2 or points.shape[1] != 4 or not points.is_contiguous():
         raise ValueError("project_points: points must be contiguous [N,4]")
@@ -598,7 +911,8 @@ def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down
     cells = torch.empty((N, 2), device=dev, dtype=torch.int32) if return_cells else None
     check(lib().lc_project_points(points.data_ptr(), N, H, W, float(fov_up), float(fov_down),
                                   float(min_depth), float(max_depth), zbuf.data_ptr(),
-                                  img.data_ptr(), win.data_ptr(), _p(cells), _stream()),
+                                  img.data_ptr(), win.data_ptr(), _p(cells),
+                                  1 if mode == "native" else 0, _stream()),
           "lc_project_points")
     return (img, win, cells) if return_cells else (img, win)
 
@@ -860,3 +1174,20 @@ def layout_condition(boxes: torch.Tensor, n_valid: torch.Tensor, H: int, W: int,
                                     c2d.data_ptr(), mask.data_ptr(), _p(wmap), _stream()),
           "lc_layout_condition")
     return (c2d, mask, wmap) if with_weight_map else (c2d, mask)
+
+
+# ------------------------------------------------------------------------------------ boundary
+# every public op goes through `_entry` (device guard + up-cast of half-precision inputs)
+def _wrap_public_ops():
+    import types
+
+    g = globals()
+    skip = {"fuse_gn", "set_conv_precision", "range_poll", "range_checked", "defer_range_checks",
+            "name_packed_convs", "rng_snapshot", "rng_restore", "run_range_safe"}
+    for name, obj in list(g.items()):
+        if isinstance(obj, types.FunctionType) and not name.startswith("_") and name not in skip \
+                and obj.__module__ == __name__ and not getattr(obj, "_lc_entry", False):
+            g[name] = _entry(obj)
+
+
+_wrap_public_ops()

@@ -342,6 +342,112 @@ def sec_c4():
     save("c4_64x2048", **out)
 
 
+def sec_rng_state():
+    """Generator state after `sample()` (base.py:73-96, continuous_time.py:226-231: DDIM eta=0 still
+    draws randn_like every step): 4 numbers drawn from each per-sample generator AFTER a 3-step
+    run of the reduced model, for ddim and ddpm."""
+    eu = R.ref("models.unets.efficient_unet")
+    df = R.ref("models.diffusion")
+    m = _build_uncond(eu, 16, (8, 64))
+    ddpm = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval()
+    out = {}
+    for mode in ("ddim", "ddpm"):
+        rng = [torch.Generator().manual_seed(500 + i) for i in range(2)]
+        out[f"{mode}_x"] = ddpm.sample(2, 3, progress=False, rng=rng, mode=mode)
+        out[f"{mode}_next"] = torch.stack([torch.randn(4, generator=g) for g in rng])
+        one = torch.Generator().manual_seed(510)
+        ddpm.sample(2, 3, progress=False, rng=one, mode=mode)
+        out[f"{mode}_next_one"] = torch.randn(4, generator=one)
+    save("rng_state", **out)
+
+
+def sec_render():
+    """lidargen/utils/render.py: bilinear_rasterizer :83-142, estimate_surface_normal :145-236,
+    colorize :239-246 (the functions that do not call kornia; the module is imported with an EMPTY
+    stand-in for the absent `kornia` import line only -- make_Rt / render_point_clouds, which do call
+    it, are not pinned), and lidargen/utils/training.py:7-24 (LR multipliers)."""
+    import types
+    import matplotlib.cm as cm
+
+    k = types.ModuleType("kornia")
+    k.geometry = types.ModuleType("kornia.geometry")
+    k.geometry.conversions = types.ModuleType("kornia.geometry.conversions")
+    k.geometry.conversions.axis_angle_to_rotation_matrix = None
+    sys.modules.update({"kornia": k, "kornia.geometry": k.geometry,
+                        "kornia.geometry.conversions": k.geometry.conversions})
+    rd = R.ref("utils.render")
+    tr = R.ref("utils.training")
+    out = {}
+    g = torch.Generator().manual_seed(90)
+    coords = torch.rand(2, 500, 2, generator=g) * 40 - 4          # some outside the 32x32 image
+    vals = torch.rand(2, 500, 3, generator=g)
+    out["splat"] = rd.bilinear_rasterizer(coords, vals, (32, 32))
+    pts = seeded_randn(2, 3, 16, 64, seed=91).cumsum(-1)
+    out["normal_closest"] = rd.estimate_surface_normal(pts, d=2, mode="closest")
+    out["normal_mean"] = rd.estimate_surface_normal(pts, d=1, mode="mean")
+    v = torch.rand(2, 1, 8, 16, generator=g) * 1.2 - 0.1
+    out["color_turbo"] = rd.colorize(v)
+    out["color_viridis"] = rd.colorize(v[:, 0], cm.viridis)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = tr.get_cosine_schedule_with_warmup(opt, num_warmup_steps=5, num_training_steps=40)
+    lrs = []
+    for _ in range(45):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    out["lr"] = np.array(lrs)
+    save("render", **out)
+
+
+def sec_caller_names():
+    """NAMES ONLY: every `lidargen.*` module / attribute the reference's caller scripts touch
+    (tools/generate/generate.py, generate_cond.py, tools/train/train_lidm.py, train_lidm_cond.py,
+    tools/evaluation/sample_and_save_cond.py, sample_and_save_temporal.py), extracted with `ast`;
+    committed as tests/golden/caller_names.json and resolved against this build by a CPU test."""
+    import ast
+    import json
+
+    scripts = ["tools/generate/generate.py", "tools/generate/generate_cond.py",
+               "tools/train/train_lidm.py", "tools/train/train_lidm_cond.py",
+               "tools/evaluation/sample_and_save_cond.py",
+               "tools/evaluation/sample_and_save_temporal.py"]
+    res = {}
+    for sc in scripts:
+        tree = ast.parse(open(os.path.join(R.REF, sc)).read())
+        alias, names = {}, set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "lidargen":
+                for a in node.names:
+                    names.add(f"{node.module}.{a.name}")
+                    alias[a.asname or a.name] = f"{node.module}.{a.name}"
+            elif isinstance(node, ast.Import):
+                for a in node.names:
+                    if a.name.split(".")[0] == "lidargen":
+                        names.add(a.name)
+                        alias[a.asname or a.name] = a.name
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and \
+                    node.value.id in alias and not alias[node.value.id].endswith("__all__"):
+                names.add(f"{alias[node.value.id]}.{node.attr}")
+        # attribute chains on the objects the factory returns (cfg.training.lr, ddpm.sample, ...)
+        roots = {"cfg": "cfg", "auto_cfg": "cfg", "ddpm": "ddpm", "auto_ddpm": "ddpm",
+                 "lidar_utils": "lidar_utils", "model": "model"}
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute):
+                chain, cur = [], node
+                while isinstance(cur, ast.Attribute):
+                    chain.append(cur.attr)
+                    cur = cur.value
+                if isinstance(cur, ast.Name) and cur.id in roots:
+                    chain = list(reversed(chain))
+                    keep = chain[:2] if roots[cur.id] == "cfg" else chain[:1]
+                    names.add("@" + roots[cur.id] + "." + ".".join(keep))
+        res[sc] = sorted(names)
+    path = os.path.join(HERE, "caller_names.json")
+    json.dump(res, open(path, "w"), indent=1)
+    print("caller_names.json", {k: len(v) for k, v in res.items()})
+
+
 def synth_boxes(n, pts, seed):
     from lidarcrafter_amd.testing import synth_boxes as f
     return f(n, pts, seed)

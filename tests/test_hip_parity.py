@@ -31,8 +31,7 @@ def dev():
     (2, 42, 64, 8, 64, 3), (1, 512, 256, 4, 128, 1), (2, 48, 144, 1, 8, 3), (3, 16, 32, 2, 16, 3),
     (2, 64, 96, 1, 2048, 1), (1, 32, 64, 1, 192, 1),
 ])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 223, 423, 425, 412, 212, 28, 228,
-                                 33, 233, 433])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 223, 423, 425, 412, 212, 28, 228])
 @pytest.mark.parametrize("prec", ["f32", "f16x2"])
 def test_conv(dev, B, Ci, Co, H, W, ks, cfg, prec):
     from lidarcrafter_amd import ops as K
@@ -40,8 +39,6 @@ def test_conv(dev, B, Ci, Co, H, W, ks, cfg, prec):
 
     if prec == "f32" and cfg > 5:
         pytest.skip("pipelined tile configurations exist for the f16x2 kernel only")
-    if cfg % 100 == 33 and ks != 3:
-        pytest.skip("the warp-specialised kernel is a 3x3 kernel")
     x = seeded_randn(B, Ci, H, W, seed=1)
     w = seeded_randn(Co, Ci, ks, ks, seed=2) / (Ci * ks * ks) ** 0.5
     b = seeded_randn(Co, seed=3)
@@ -72,14 +69,12 @@ def test_conv_f16x2_accuracy_vs_fp64(dev):
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks,G", [(2, 64, 64, 8, 128, 3, 8), (1, 256, 128, 8, 256, 3, 32),
                                               (2, 48, 32, 4, 64, 3, 8), (2, 512, 96, 4, 128, 1, 32),
                                               (1, 128, 64, 32, 1024, 3, 8)])
-@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25, 423, 225, 33, 433])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25, 423, 225])
 def test_conv_fused_groupnorm(dev, B, Ci, Co, H, W, ks, G, cfg):
     """GN(+AdaGN scale/shift)+SiLU applied inside the conv staging == GN kernel then conv."""
     from lidarcrafter_amd import ops as K
     from oracle import denoiser as D
 
-    if cfg % 100 == 33 and ks != 3:
-        pytest.skip("the warp-specialised kernel is a 3x3 kernel")
 
     x = seeded_randn(B, Ci, H, W, seed=50) * 1.3 + 0.4
     w = seeded_randn(Co, Ci, ks, ks, seed=51) / (Ci * ks * ks) ** 0.5
@@ -235,7 +230,7 @@ def test_groupnorm_concat_segments_and_invalidation(dev):
     assert K._find_stats(y, G) is None
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 5, 13, 23, 25, 28, 223, 33])
+@pytest.mark.parametrize("cfg", [0, 3, 5, 13, 23, 25, 28, 223])
 @pytest.mark.parametrize("B,C,H,W,G,ks", [(2, 64, 16, 128, 8, 3), (1, 64, 32, 1024, 8, 3),
                                           (2, 64, 5, 72, 4, 3), (2, 64, 8, 64, 8, 1)])
 def test_conv_fused_groupnorm_from_producer_stats(dev, B, C, H, W, G, ks, cfg):
@@ -483,25 +478,38 @@ def test_projection_bit_exact(dev, N, H, W, seed):
     if N == 7:  # duplicates -> equal-depth ties: lowest index wins
         pts[3] = pts[1]
         pts[5] = pts[1]
-    img_r, win_r = L.load_points_as_images(pts, H, W, mode="f32")
-    gh, gw, _ = L.project_cells(pts, H, W, 10.0, -30.0, "f32")
-    img, win, cells = K.project_points(T(pts).to(dev), H, W, 10.0, -30.0, 1.45, 80.0,
-                                       return_cells=True)
-    assert np.array_equal(cells.cpu().numpy(), np.stack([gh, gw], 1).reshape(-1, 2))
-    assert np.array_equal(win.cpu().numpy(), win_r)
-    assert np.array_equal(img.cpu().numpy(), img_r)
+    # both dtype contracts: "native" (default: float64 elevation arithmetic, the reference under
+    # numpy >= 2) and "f32" (the reference's pinned numpy 1.23.5), bit-exact vs the oracle
+    for mode, omode in (("native", "native_cr"), ("f32", "f32")):
+        img_r, win_r = L.load_points_as_images(pts, H, W, mode=omode)
+        gh, gw, _ = L.project_cells(pts, H, W, 10.0, -30.0, omode)
+        img, win, cells = K.project_points(T(pts).to(dev), H, W, 10.0, -30.0, 1.45, 80.0,
+                                           return_cells=True, dtype_mode=mode)
+        assert np.array_equal(cells.cpu().numpy(), np.stack([gh, gw], 1).reshape(-1, 2)), mode
+        assert np.array_equal(win.cpu().numpy(), win_r), mode
+        assert np.array_equal(img.cpu().numpy(), img_r), mode
 
 
-def test_projection_vs_reference_golden(dev, golden):
-    """Against the reference as run in the build container (numpy 2 promotion): identical except
-    for boundary points whose float64-vs-float32 elevation differs."""
+@pytest.mark.parametrize("tag,N,H,W,seed", [("a", 4096, 16, 256, 0), ("b", 34720, 32, 1024, 1)])
+def test_projection_vs_reference_golden(dev, golden, tag, N, H, W, seed):
+    """Against the reference AS RUN in the build container (numpy 2.2 promotion, fixture
+    tests/golden/lidar.npz): 0 differing cells, all four stored channels bit-identical.  (The
+    kernel's asin / atan2 are correctly rounded, numpy's SIMD float32 ones are not; a difference
+    could only appear in a cell reachable by a point whose cell depends on that last bit --
+    oracle.lidar.ulp_ambiguous -- and these fixtures have none that matters.)"""
     from lidarcrafter_amd import ops as K
+    from oracle import lidar as L
 
     g = golden("lidar")
-    pts = synth_points(34720, 1)
-    img, _ = K.project_points(T(pts).to(dev), 32, 1024, 10.0, -30.0, 1.45, 80.0)
-    diff = (img[..., 4].cpu().numpy() != g["proj_b_depth"]).sum()
-    assert diff <= 16, diff
+    pts = synth_points(N, seed)
+    img = K.project_points(T(pts).to(dev), H, W, 10.0, -30.0, 1.45, 80.0)[0].cpu().numpy()
+    diff = np.argwhere(img[..., 4] != g[f"proj_{tag}_depth"]).tolist()
+    _, cells = L.ulp_ambiguous(pts, H, W, 10.0, -30.0)
+    assert all((a, b) in cells for a, b in diff), diff
+    assert diff == [], diff
+    assert np.array_equal(img[..., 5].astype(np.uint8), g[f"proj_{tag}_mask"])
+    assert np.array_equal(img[..., 0], g[f"proj_{tag}_x"])
+    assert np.array_equal(img[..., 3], g[f"proj_{tag}_i"])
 
 
 # ------------------------------------------------------------------------------------- conditional
@@ -603,7 +611,7 @@ def test_load_points_as_images_api(dev, golden):
 
     pts = synth_points(4096, 0)
     img = load_points_as_images(points=pts, scan_unfolding=False, H=16, W=256)
-    ref, _ = L.load_points_as_images(pts, 16, 256, mode="f32")
+    ref, _ = L.load_points_as_images(pts, 16, 256, mode="native_cr")
     assert isinstance(img, np.ndarray) and np.array_equal(img, ref)
 
 

@@ -45,7 +45,7 @@ def _worker(rank, world, port, gb, q):
         x = ddpm.randn(len(rng), *ddpm.sampling_shape, rng=rng, device="cpu")
         x = x + 0.0 * rank
         full = parallel.gather_frames(x, gb)
-        q.put((rank, full))
+        q.put((rank, full.numpy().copy()))   # by value: a shared-fd tensor dies with the worker
     finally:
         dist.destroy_process_group()
 
@@ -61,7 +61,7 @@ def _run_two_ranks(gb):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, gb, q)) for r in range(2)]
     [p.start() for p in procs]
     try:
-        got = dict(q.get(timeout=300) for _ in range(2))
+        got = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in range(2))}
     except queue.Empty:
         got = None
     [p.join(timeout=60) for p in procs]
