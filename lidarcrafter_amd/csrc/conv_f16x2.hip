@@ -50,6 +50,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_ABLATE
 #define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
 #endif
+#ifndef LC_F16X2_TERMS
+// which of the three products are accumulated: bit 0 wh*xh, bit 1 wl*xh, bit 2 wh*xl.  7 in the
+// product; 1 / 3 / 5 exist only to MEASURE what fewer passes cost in accuracy
+// (devtools/passes_error.py, profiles/r02_passes_error.json).
+#define LC_F16X2_TERMS 7
+#endif
 constexpr float X_PRESCALE_DEFAULT = 16.0f, W_PRESCALE_DEFAULT = 256.0f;
 
 struct ConvArgsH {
@@ -380,8 +386,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
             for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll
                 for (int j = 0; j < C::TPX_; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (LC_F16X2_TERMS & 2)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (LC_F16X2_TERMS & 4)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -652,16 +660,20 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
             for (int i = 0; i < NWU; ++i)
                 if (tap == store_tap_w(i)) store_w(nxt, wr, i);
+            if (LC_F16X2_TERMS & 2) {
 #pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
+                for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::TPX_; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+            }
+            if (LC_F16X2_TERMS & 4) {
 #pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
+                for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::TPX_; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll
