@@ -1,0 +1,9 @@
+#!/bin/bash
+# developer builds with a -D switch: bash devtools/build_abl.sh NAME "-DLC_X=1 ..."  -> devtools/variants/liblc_NAME.so
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p devtools/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c lidarcrafter_amd/csrc/conv_f16x2.hip -o devtools/variants/conv_$1.o 2>/dev/null
+objs=$(ls lidarcrafter_amd/build/*.o | grep -v conv_f16x2.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o devtools/variants/liblc_$1.so $objs devtools/variants/conv_$1.o
+echo built devtools/variants/liblc_$1.so

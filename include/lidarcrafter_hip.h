@@ -233,6 +233,15 @@ int lc_pstep_fwd(const float* x_t, int64_t xt_bs, const float* pred, int64_t pre
                  const float* noise, int64_t noise_bs, const float* coef, float* x_s,
                  int64_t xs_bs, int B, int64_t n, int objective, int mode, lc_stream_t s);
 
+/* Point Condition Network epilogue of the foreground-object denoiser
+ * (lidargen/models/unets/point_unet.py:14-26, PCNet): channel-major rows [B, C, N],
+ *   y = act( x * sigmoid(gate_logit[b,c]) + bias[b,c] ) [+ res],  act: 0 none, 1 leaky_relu(0.01)
+ * x = fea_layer(fea) from lc_conv2d_ring_*_fwd (1x1); gate_logit / bias rows [B, >=C] with row
+ * stride gb_bs (slices of ONE batched cond_gate | cond_bias projection); res may be NULL. */
+int lc_gate_bias_act(const float* x, int64_t x_bs, const float* gate_logit, const float* bias,
+                     int64_t gb_bs, const float* res, int64_t res_bs, float* y, int64_t y_bs,
+                     int B, int C, int N, int act, lc_stream_t s);
+
 /* Strided copy of [B, C*H*W] blocks (fills a channel slice of a concat buffer). */
 int lc_copy_strided(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int64_t n,
                     lc_stream_t s);

@@ -211,26 +211,47 @@ struct HCfg {
 // lo = fp16(s - hi) (RTNE; subnormal below 2^-14, zero below 2^-25).  `am` accumulates max |s|.
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
+#ifndef LC_SPLIT_ABL
+#define LC_SPLIT_ABL 0   // developer ablation: 1 no amax accumulation, 2 round-to-nearest split
+#endif
+template <bool NOPACK>
 __device__ __forceinline__ void split_pair(float v0, float v1, float xs, h2_t& ph, h2_t& pl, float& am) {
-    const float s0 = v0 * xs, s1 = v1 * xs;
-    am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(s0), __builtin_fabsf(s1)));   // v_max3_f32
+    float s0 = v0 * xs, s1 = v1 * xs;
+    // NOPACK: keep hipcc's SLP vectoriser from fusing the two multiplies into v_pk_mul_f32 -- the
+    // packed form needs an aligned register pair, and in the 2-blocks/CU kernel the v_mov_b64 that
+    // builds it (with its s_waitcnt) lands between the global loads of the next chunk and
+    // serialises them (1x1 convs 26 -> 35 us, 33 -> 61 us, measured r02g)
+    if (NOPACK) asm volatile("" : "+v"(s0), "+v"(s1));
+    if (!(LC_SPLIT_ABL & 1))
+        am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(s0), __builtin_fabsf(s1)));   // v_max3_f32
+    if (LC_SPLIT_ABL & 2) {
+        const _Float16 a0 = (_Float16)s0, a1 = (_Float16)s1;
+        ph.x = a0; ph.y = a1;
+        pl.x = (_Float16)(s0 - (float)a0); pl.y = (_Float16)(s1 - (float)a1);
+        return;
+    }
     const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
     const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
     ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
     f2_t r; r.x = s0 - h0; r.y = s1 - h1;
     pl = __builtin_convertvector(r, h2_t);
 }
+template <bool NOPACK = false>
 __device__ __forceinline__ void split8(const float (&v)[8], float xs, half8& hi, half8& lo, float& am) {
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {
         h2_t ph, pl;
-        split_pair(v[k], v[k + 1], xs, ph, pl, am);
+        split_pair<NOPACK>(v[k], v[k + 1], xs, ph, pl, am);
         hi[k] = ph.x; hi[k + 1] = ph.y; lo[k] = pl.x; lo[k + 1] = pl.y;
     }
 }
 // publish the wave's max |x * x_scale| (am >= 0: unsigned order == float order); a cached read
 // keeps all but the first few blocks of a launch off the atomic
+#ifndef LC_RANGE_ABL
+#define LC_RANGE_ABL 0   // developer ablation: 1 no amax publish, 2 constant scales (no device loads)
+#endif
 __device__ __forceinline__ void publish_amax(lc_conv_range* rg, float am, float seen) {
+    if (LC_RANGE_ABL & 1) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o, 64));
     if ((threadIdx.x & 63) == 0 && am > seen)
@@ -264,9 +285,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     const int H = a.H, W = a.W;
     const long long HW = (long long)H * W;
     const float* xb = a.x + (long long)b * a.x_bs;
-    const float xs = a.range->x_scale;
-    const float amax_seen = a.range->amax_scaled;
-    const float out_unscale = a.range->x_unscale * a.wmeta[1];
+    const float xs = (LC_RANGE_ABL & 2) ? 16.0f : a.range->x_scale;
+    const float amax_seen = (LC_RANGE_ABL & 2) ? 0.0f : a.range->amax_scaled;
+    const float out_unscale = (LC_RANGE_ABL & 2) ? 1.0f / 4096.0f : a.range->x_unscale * a.wmeta[1];
     float am = 0.0f;
 
     int x_off[NXU];  // (cb << 24 | plane offset) or -1 for padding
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
                     for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu);
                 }
                 half8 hi, lo;
-                split8(xr[i], xs, hi, lo, am);
+                split8<true>(xr[i], xs, hi, lo, am);
                 xh[e] = hi;
                 xl[e] = lo;
             }

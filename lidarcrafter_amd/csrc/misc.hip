@@ -55,6 +55,30 @@ __global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__
     y[(long long)m * channels + half + k] = cosf(a);
 }
 
+// Point Condition Network epilogue (point_unet.py:22-26): per (sample, channel) row of N points
+//   y = act( x * sigmoid(gate_logit[b,c]) + bias[b,c] ) [+ res]
+// x = fea_layer(fea) in channel-major layout [B, C, N] (the 1x1-conv kernel's output).
+__global__ __launch_bounds__(256) void gate_bias_kernel(const float* __restrict__ x, long long x_bs,
+                                                       const float* __restrict__ gate_logit,
+                                                       const float* __restrict__ bias,
+                                                       long long gb_bs,
+                                                       const float* __restrict__ res,
+                                                       long long res_bs, float* __restrict__ y,
+                                                       long long y_bs, int C, int N, int act) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float g = 1.0f / (1.0f + expf(-gate_logit[b * gb_bs + c]));
+    const float s = bias[b * gb_bs + c];
+    const float* xr = x + b * x_bs + (long long)c * N;
+    const float* rr = res ? res + b * res_bs + (long long)c * N : nullptr;
+    float* yr = y + b * y_bs + (long long)c * N;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float v = xr[n] * g + s;
+        if (act == 1) v = v > 0.f ? v : 0.01f * v;          // F.leaky_relu default slope
+        if (rr) v += rr[n];
+        yr[n] = v;
+    }
+}
+
 #pragma clang fp contract(off)
 // continuous_time.py:209-231; same op order as the reference so fp32 rounding agrees.
 __global__ __launch_bounds__(256) void pstep_kernel(
@@ -180,5 +204,16 @@ extern "C" int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_
     if (!a || !b || !y || B <= 0 || n <= 0) return LC_EINVAL;
     hipLaunchKernelGGL(add_scale_kernel, dim3(grid_for(n), B), dim3(256), 0, lc_s(s), a,
                        (long long)a_bs, b, (long long)b_bs, y, (long long)y_bs, (long long)n, scale);
+    return lc_launch_status();
+}
+
+extern "C" int lc_gate_bias_act(const float* x, int64_t x_bs, const float* gate_logit,
+                                const float* bias, int64_t gb_bs, const float* res, int64_t res_bs,
+                                float* y, int64_t y_bs, int B, int C, int N, int act, lc_stream_t s) {
+    if (!x || !gate_logit || !bias || !y || B <= 0 || C <= 0 || N <= 0 || act < 0 || act > 1)
+        return LC_EINVAL;
+    hipLaunchKernelGGL(gate_bias_kernel, dim3(C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
+                       gate_logit, bias, (long long)gb_bs, res, (long long)res_bs, y,
+                       (long long)y_bs, C, N, act);
     return lc_launch_status();
 }

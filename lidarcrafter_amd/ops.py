@@ -265,14 +265,19 @@ class ConvRangeError(ArithmeticError):
 class _RangeArena:
     def __init__(self, device):
         self.device = device
-        init = torch.zeros((RANGE_SLOTS, 4), dtype=_F32)
-        init[:, 0], init[:, 1] = X_SCALE_DEFAULT, 1.0 / X_SCALE_DEFAULT
-        self.buf = init.to(device)
+        # (a NORMAL tensor even when the first conv runs under torch.inference_mode(): the poll
+        #  updates it in place from any mode)
+        with torch.inference_mode(False):
+            init = torch.zeros((RANGE_SLOTS, 4), dtype=_F32)
+            init[:, 0], init[:, 1] = X_SCALE_DEFAULT, 1.0 / X_SCALE_DEFAULT
+            self.buf = init.to(device)
         self.scale = [X_SCALE_DEFAULT] * RANGE_SLOTS      # host mirror of x_scale
         self.free = list(range(RANGE_SLOTS - 1, -1, -1))
         self.owner = {}                                    # slot -> weakref to the owning PackedConv
-        self.host = torch.empty((RANGE_SLOTS, 4), dtype=_F32).pin_memory() if device.type == "cuda" \
-            else torch.empty((RANGE_SLOTS, 4), dtype=_F32)
+        with torch.inference_mode(False):
+            self.host = torch.empty((RANGE_SLOTS, 4), dtype=_F32)
+            if device.type == "cuda":
+                self.host = self.host.pin_memory()
 
     def alloc(self, owner) -> int:
         import weakref
@@ -859,6 +864,30 @@ def pstep(x_t, pred, noise, coef, objective: int, mode: int, out=None) -> torch.
     check(lib().lc_pstep_fwd(x_t.data_ptr(), xb, pred.data_ptr(), pb, _p(noise), nb,
                              coef.data_ptr(), out.data_ptr(), ob, B, C * H * W, objective, mode,
                              _stream()), "lc_pstep_fwd")
+    return out
+
+
+def gate_bias_act(x: torch.Tensor, gate_logit: torch.Tensor, bias: torch.Tensor, leaky: bool,
+                  res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PCNet epilogue (reference point_unet.py:22-26) on channel-major rows x [B, C, N]:
+    y = act(x * sigmoid(gate_logit[b, c]) + bias[b, c]) [+ res]; gate_logit / bias: [B, C] views of
+    one wider projection (equal row stride, unit inner stride)."""
+    _req(x, "x"), _req(gate_logit, "gate_logit"), _req(bias, "bias")
+    if x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("gate_bias_act: x must be contiguous [B, C, N]")
+    B, C, N = x.shape
+    if gate_logit.shape != (B, C) or bias.shape != (B, C) or gate_logit.stride(1) != 1 or \
+            bias.stride(1) != 1 or gate_logit.stride(0) != bias.stride(0):
+        raise ValueError("gate_bias_act: gate_logit / bias must be [B, C] with equal row strides")
+    if res is not None:
+        _req(res, "res")
+        if res.shape != x.shape or not res.is_contiguous():
+            raise ValueError("gate_bias_act: res must be contiguous and shaped like x")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().lc_gate_bias_act(x.data_ptr(), C * N, gate_logit.data_ptr(), bias.data_ptr(),
+                                 gate_logit.stride(0), _p(res), C * N, out.data_ptr(), C * N, B, C,
+                                 N, 1 if leaky else 0, _stream()), "lc_gate_bias_act")
     return out
 
 

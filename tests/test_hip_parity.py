@@ -169,8 +169,7 @@ def test_groupnorm(dev, B, C, H, W, G, mode):
     (2, 64, 128, 16, 128, 3, 8, 0), (2, 64, 128, 16, 128, 3, 8, 23), (2, 64, 64, 16, 128, 3, 8, 423),
     (1, 128, 256, 8, 256, 3, 32, 25), (2, 48, 96, 5, 50, 3, 4, 13), (1, 64, 72, 3, 100, 3, 3, 15),
     (1, 64, 64, 32, 1024, 3, 8, 0), (2, 64, 512, 4, 128, 3, 8, 0), (1, 32, 64, 9, 70, 3, 8, 22),
-    (2, 64, 128, 16, 128, 3, 8, 28), (2, 64, 128, 16, 128, 3, 8, 33), (1, 32, 64, 9, 70, 3, 8, 33),
-    (1, 64, 64, 32, 1024, 3, 8, 433),
+    (2, 64, 128, 16, 128, 3, 8, 28), (1, 64, 64, 32, 1024, 3, 8, 423),
 ])
 def test_groupnorm_from_conv_epilogue_stats(dev, B, Ci, Co, H, W, ks, G, cfg):
     """The octet statistics emitted by the pipelined conv's epilogue drive GroupNorm to the same

@@ -58,9 +58,11 @@ def test_conv_any_magnitude(dev, xs, ws, cfg):
     amax = float(x.abs().max())
     if amax * 16 >= 65504 or amax * 16 < 2 ** -3:
         assert n_bad >= 1, "saturated / vanishing operands went unreported"
-    # a second call at the same magnitude is clean (the layer keeps its scale)
+    # further calls at the same magnitude are clean, and bit-stable once the scale has settled (a
+    # first poll may move a merely sub-optimal scale without invalidating what was computed)
     y2, n_bad2 = checked_conv(K, x.to(dev), pk, w.to(dev), tile_cfg=cfg)
-    assert n_bad2 == 0 and torch.equal(y, y2)
+    y3, n_bad3 = checked_conv(K, x.to(dev), pk, w.to(dev), tile_cfg=cfg)
+    assert n_bad2 == 0 and n_bad3 == 0 and rel_l2(y2, ref) < 2e-6 and torch.equal(y2, y3)
 
 
 def test_conv_outlier_dynamic_range(dev):
