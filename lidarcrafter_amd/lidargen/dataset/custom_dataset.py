@@ -16,6 +16,8 @@ from collections import defaultdict
 import numpy as np
 import torch
 
+from lidarcrafter_amd import ops as K
+
 from .transforms_3d import common
 
 
@@ -142,6 +144,38 @@ class CustomDataset:
                     for k in ("depth", "reflectance", "mask", "xyz"):
                         d.pop(k)
         return self.pre_process(d)
+
+    def unscaled_objs_3d(self, sample_index, custom_data_dict, generated_object_points,
+                         w_semantic=False):
+        """Generated foreground objects [n_obj, N, 4] (unit box frame, intensity in [-1, 1]) ->
+        scene-frame rows [n_obj * N, 4 (+ class)] -- reference nuscenes_dataset.py:215-243: scale by
+        the half extents, intensity 255 (i + 1) / 2, rotate about z by the box yaw, translate to the
+        centre.  CUDA tensor in -> CUDA tensor out: scale, rotation and translation of one object
+        are ONE 4x4 affine (lc_transform_points, evaluated in fp64, rounded once); numpy in ->
+        numpy out through the same kernel."""
+        info = custom_data_dict if custom_data_dict is not None else self.data[sample_index]
+        gt_boxes = np.asarray(info["gt_boxes"], np.float64)[1:, :7]
+        is_numpy = isinstance(generated_object_points, np.ndarray)
+        pts = (torch.from_numpy(np.ascontiguousarray(generated_object_points, np.float32)).cuda()
+               if is_numpy else generated_object_points.float())
+        assert gt_boxes.shape[0] == pts.shape[0]
+        classes = None
+        if w_semantic:
+            names = list(info["gt_names"])[1:]
+            classes = [self.cfg.class_names.index(n) + 1 for n in names]
+        rows = []
+        for k, box in enumerate(gt_boxes):
+            c, s_ = np.cos(box[6]), np.sin(box[6])
+            sx, sy, sz = box[3] / 2.0, box[4] / 2.0, box[5] / 2.0
+            T = np.array([[c * sx, -s_ * sy, 0.0, box[0]], [s_ * sx, c * sy, 0.0, box[1]],
+                          [0.0, 0.0, sz, box[2]], [0.0, 0.0, 0.0, 1.0]])
+            p = K.transform_points(pts[k].contiguous(), T)
+            p[:, 3] = 255 * (p[:, 3] + 1) / 2
+            if classes is not None:
+                p = torch.cat([p, torch.full((p.shape[0], 1), float(classes[k]), device=p.device)], 1)
+            rows.append(p)
+        out = torch.cat(rows, 0)
+        return out.cpu().numpy() if is_numpy else out
 
     def collate_fn(self, batch_list, _unused=False):
         data = defaultdict(list)

@@ -15,5 +15,4 @@ def _out_of_scope(name, why):
 # registry names of the reference (models/diffusion/__init__.py:1-6) must resolve
 CondContinuousLayoutGaussianDiffusion = _out_of_scope(
     "CondContinuousLayoutGaussianDiffusion", "diffusion over per-object layout vectors")
-CondContinuousLayoutGaussianDiffusion1D = _out_of_scope(
-    "CondContinuousLayoutGaussianDiffusion1D", "diffusion over per-object point sets")
+from .continuous_time_1d_cond import CondContinuousLayoutGaussianDiffusion1D  # noqa: E402

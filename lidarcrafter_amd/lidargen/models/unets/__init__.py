@@ -1,5 +1,6 @@
 """Denoiser registry: the 14 names of the reference (lidargen/models/unets/__init__.py:15-30).
-On the hot path: efficient_unet, layout_unet_v1, layout_encoder.  Everything else is OUT OF SCOPE
+On the hot path: efficient_unet, layout_unet_v1, layout_encoder, and the foreground-object branch
+of SURVEY.md §8f-3 (point_unet, object_gen_encoder).  Everything else is OUT OF SCOPE
  and resolves to a stub whose constructor says so."""
 from .efficient_unet import EfficientUNet
 
@@ -29,8 +30,8 @@ SceneGraph = _stub("SceneGraph", "scene-graph GCN of the layout generator")
 SpatialRescaler = _stub("SpatialRescaler", "LDM helper")
 Identity = _stub("Identity", "LDM helper")
 OpenAIUNetModel = _stub("OpenAIUNetModel", "LDM-style UNet")
-ObjectGenEncoder = _stub("ObjectGenEncoder", "foreground-object branch (SURVEY.md §8f-3)")
-PointUNet = _stub("PointUNet", "foreground-object point denoiser (SURVEY.md §8f-3)")
+from .encoders.object_gen_encoder import ObjectGenEncoder  # noqa: E402
+from .point_unet import PointUNet  # noqa: E402
 
 __all__ = {
     "layout_encoder": LayoutTransformerEncoder,

@@ -206,6 +206,11 @@ MeanFlow_NUSC_Config = make_config("MeanFlow_NUSC_Config", model_arch="mf_effici
 NUSC_Layout_Config = make_config("NUSC_Layout_Config", model_arch="unet_1d", model_params={},
                                  cond_arch="scene_graph", cond_params={},
                                  data=dict(task="layout_generation"))
-NUSC_Object_Config = make_config("NUSC_Object_Config", model_arch="point_unet", model_params={},
-                                 cond_arch="object_gen_encoder", cond_params={},
-                                 data=dict(task="object_generation"))
+# foreground-object branch (option_nusc_object.py): PointUNet over [1024, 4] object points
+NUSC_Object_Config = make_config(
+    "NUSC_Object_Config", model_arch="point_unet", model_params=dict(point_dim=4, cond_dims=768),
+    cond_arch="object_gen_encoder", cond_params=dict(num_class=8),
+    data=dict(task="object_generation", dataset="nuscenes-object", custom_collate_fn=True,
+              pkl_path="../data/infos/nuscenes_dbinfos_10sweeps_withvelo.pkl"),
+    diffusion=dict(clip_sample=False),
+    training=dict(num_steps=1_000_000, steps_save_model=100_000))

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..models.diffusion import (CondContinuousTimeGaussianDiffusion,
+from ..models.diffusion import (CondContinuousLayoutGaussianDiffusion1D,
+                                CondContinuousTimeGaussianDiffusion,
                                 ContinuousTimeGaussianDiffusion, DiscreteTimeGaussianDiffusion)
 from ..models.unets import __all__ as __all_unets__
 from .configs import __all__
@@ -90,6 +91,25 @@ def load_model_duffusion_training(cfg: object):
     ddpm.load_state_dict(ckpt["ema_weights"])
     ddpm.eval()
     return ddpm, model, lidar_utils, ckpt["global_step"], ckpt["optimizer"], ckpt["lr_scheduler"]
+
+
+def load_model_object_duffusion_training(cfg: object):
+    """Foreground-object branch (reference inference.py:369-390): -> (ddpm, model) or, when
+    cfg.resume is a checkpoint path, (ddpm, model, global_step, optimizer_state, lr_state)."""
+    model = __all_unets__[cfg.model.architecture](**cfg.model.params)
+    cond = __all_unets__[cfg.condition_model.architecture](**cfg.condition_model.params)
+    d = cfg.diffusion
+    ddpm = CondContinuousLayoutGaussianDiffusion1D(
+        model=model, condition_model=cond, loss_type=d.loss_type,
+        prediction_type=d.prediction_type, noise_schedule=d.noise_schedule,
+        clip_sample=d.clip_sample)
+    ckpt_path = getattr(cfg, "resume", None)
+    if ckpt_path is None:
+        return ddpm, model
+    ckpt = torch.load(ckpt_path, map_location="cpu")
+    ddpm.load_state_dict(ckpt["ema_weights"])
+    ddpm.eval()
+    return ddpm, model, ckpt["global_step"], ckpt["optimizer"], ckpt["lr_scheduler"]
 
 
 def setup_model(cfg: str, ckpt, device="cpu", ema: bool = True, show_info: bool = True,

@@ -146,3 +146,23 @@ def synth_temporal_inputs(seed=0, K=5, T=6):
     boxes = np.stack([r * np.cos(az), r * np.sin(az), g.uniform(-1.5, 0.0, K), g.uniform(1.5, 6, K),
                       g.uniform(1.2, 2.5, K), g.uniform(1.2, 2.5, K), g.uniform(-np.pi, np.pi, K)], 1)
     return trajs, boxes
+
+
+def synth_object_batch(B: int, seed: int) -> dict:
+    """Synthetic foreground-object condition batch: box codes `fg_encoding_box`
+    [B, 6] = (x, y, z, l, w, unique yaw) in the scaled ranges of nuscenes_dataset.encoding_boxes_3d
+    and class ids `fg_class` [B] in 0..7."""
+    g = torch.Generator().manual_seed(seed)
+    box = torch.rand(B, 6, generator=g) * 2 - 1
+    cls = torch.randint(0, 8, (B,), generator=g)
+    return {"fg_encoding_box": box, "fg_class": cls}
+
+
+def synth_text_features(seed: int = 77) -> dict:
+    """Stand-in for the CLIP class-name features of obj_text_feat.pkl (8 x 512, unit norm)."""
+    names = ["car", "truck", "construction_vehicle", "bus", "trailer", "motorcycle", "bicycle",
+             "pedestrian"]
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn(8, 512, generator=g)
+    f = f / f.norm(dim=1, keepdim=True)
+    return {n: f[i] for i, n in enumerate(names)}

@@ -74,7 +74,7 @@ def p_step(denoise, x_t, step_t, step_s, noise, *, mode="ddpm", ddim_eta=0.0, ob
 
 @torch.no_grad()
 def sample(denoise, shape, num_steps, rng, *, mode="ddpm", ddim_eta=0.0, objective="eps",
-           return_all=False, schedule=log_snr_cosine):
+           return_all=False, schedule=log_snr_cosine, clip=True):
     """continuous_time.py:237-260.  shape = (B, C, H, W)."""
     B = shape[0]
     x = randn(shape, rng)
@@ -83,7 +83,7 @@ def sample(denoise, shape, num_steps, rng, *, mode="ddpm", ddim_eta=0.0, objecti
     for i in range(num_steps):
         noise = randn(tuple(x.shape), rng)
         x = p_step(denoise, x, steps[:, i], steps[:, i + 1], noise, mode=mode,
-                   ddim_eta=ddim_eta, objective=objective, schedule=schedule)
+                   ddim_eta=ddim_eta, objective=objective, schedule=schedule, clip=bool(clip))
         out.append(x)
     return torch.stack(out) if return_all else x
 

@@ -448,6 +448,39 @@ def sec_caller_names():
     print("caller_names.json", {k: len(v) for k, v in res.items()})
 
 
+def sec_object():
+    """Foreground-object branch: ObjectGenEncoder (encoders/object_gen_encoder.py:7-88) with
+    synthetic class text features, PointUNet (point_unet.py:14-71) forward, and 4-step DDPM / DDIM
+    runs of CondContinuousLayoutGaussianDiffusion1D (continuous_time_1d_cond.py:9-91,
+    clip_sample=False like option_nusc_object.py)."""
+    from lidarcrafter_amd.testing import synth_object_batch, synth_text_features
+
+    pu = R.ref("models.unets.point_unet")
+    oe = R.ref("models.unets.encoders.object_gen_encoder")
+    d1 = R.ref("models.diffusion.continuous_time_1d_cond")
+    m = seeded_fill(pu.PointUNet(point_dim=4, cond_dims=768), salt=300).eval()
+    enc = seeded_fill(oe.ObjectGenEncoder(num_class=8), salt=301).eval()
+    enc.obj_text_feat = synth_text_features()
+    enc.prepare_called = True
+    batch = synth_object_batch(3, seed=95)
+    out = {}
+    with torch.no_grad():
+        cond = enc(batch)
+        out["cond"] = cond
+        x = seeded_randn(3, 1024, 4, seed=96)
+        lam = torch.tensor([-6.0, 0.5, 9.0])
+        out["unet_y"] = m(x, {"time_condition": lam, "other_condition": cond})
+    out["keys"] = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in
+                                  list(m.state_dict().items()) + [("enc." + k, v) for k, v in
+                                                                  enc.state_dict().items()]))
+    ddpm = d1.CondContinuousLayoutGaussianDiffusion1D(m, enc, clip_sample=False).eval()
+    for mode in ("ddpm", "ddim"):
+        rng = [torch.Generator().manual_seed(600 + i) for i in range(3)]
+        out[f"traj_{mode}"] = ddpm.sample(batch, 3, 4, progress=False, rng=rng, return_all=True,
+                                          mode=mode)
+    save("object", **out)
+
+
 def synth_boxes(n, pts, seed):
     from lidarcrafter_amd.testing import synth_boxes as f
     return f(n, pts, seed)
