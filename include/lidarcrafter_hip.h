@@ -250,6 +250,28 @@ int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_t b_bs, flo
                  int64_t y_bs, int B, int64_t n, float scale, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
+ * Voxel scatter of the weight-free metrics (lidargen/metrics/metric_utils.py).
+ * lc_bev_occupancy_accumulate: ONE sweep of pcd2bev_sum (:233-258): points with x in (x0, x1) and
+ *   y in (y0, y1) are binned to ix = floor(x / voxel) - min_bound_x (float32 division, as numpy),
+ *   every voxel the sweep touches gets +1 in `grid` [nx, ny] float32 -- exactly once per sweep:
+ *   `stamps` [nx*ny] int32 (zero-initialised by the caller, one per grid) holds the id of the last
+ *   sweep that touched the voxel; pass a `stamp` != 0 that differs from sweep to sweep, and run
+ *   the sweeps of one grid in stream order.  pt_stride = floats per point row (>= 2).
+ * lc_sparse_quantize (:28-66): floor(coords / voxel) -> int32 [N, D] (D = 2 or 3), unique rows in
+ *   ravel-hash (= lexicographic) order -> out_coords (first *out_count rows valid), out_index =
+ *   index of each unique row's FIRST occurrence (may be NULL), out_inverse [N] (may be NULL) --
+ *   np.unique(ravel_hash(q), return_index, return_inverse).  out_count: device uint64.
+ *   scratch: lc_sparse_quantize_scratch_bytes(N, D) bytes of device memory.
+ * ------------------------------------------------------------------------------------------- */
+int lc_bev_occupancy_accumulate(const float* pts, int pt_stride, int N, float x0, float x1, float y0,
+                                float y1, float voxel, int min_bound_x, int min_bound_y, int nx,
+                                int ny, int stamp, int32_t* stamps, float* grid, lc_stream_t s);
+int64_t lc_sparse_quantize_scratch_bytes(int N, int D);
+int lc_sparse_quantize(const float* coords, int N, int D, float vx, float vy, float vz, void* scratch,
+                       int32_t* out_coords, int64_t* out_index, int64_t* out_inverse,
+                       uint64_t* out_count, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
  * Point cloud -> range image, lidargen/dataset/transforms_3d/common.py:26-91 with
  * scan_unfolding=False: spherical cell per point, nearest point per cell wins (z-buffer via
  * 64-bit atomicMin on (depth_bits<<32 | point_idx); equal depths: lowest index wins), mask

@@ -84,6 +84,10 @@ SIGNATURES = {
     "lc_points_in_boxes_mask4": (i32, [vp, i32, vp, i32, f32, vp, vp, vp]),
     "lc_transform_points": (i32, [vp, i32, C.POINTER(C.c_double), vp, vp]),
     "lc_image_to_points": (i32, [vp, i64, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp]),
+    "lc_bev_occupancy_accumulate": (i32, [vp, i32, i32, f32, f32, f32, f32, f32, i32, i32, i32, i32,
+                                          i32, vp, vp, vp]),
+    "lc_sparse_quantize_scratch_bytes": (i64, [i32, i32]),
+    "lc_sparse_quantize": (i32, [vp, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "lc_bev_histogram": (i32, [vp, i32, i32, vp, i32, f32, f32, vp, vp, vp]),
     "lc_rbf_partials_elems": (i64, [i32, i32]),
     "lc_rbf_kernel_sum": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),

@@ -1085,6 +1085,70 @@ def bev_histogram(points: torch.Tensor, field_size: float = 160.0, bins: int = 1
     return hist
 
 
+class BevOccupancy:
+    """Accumulator of pcd2bev_sum (reference metric_utils.py:233-258): `add(points)` scatters one
+    sweep ([N, >=2] CUDA float32 rows, x / y first) into the [nx, ny] grid -- every voxel a sweep
+    touches counts once -- with lc_bev_occupancy_accumulate; `grid` is the float32 volume sum."""
+
+    def __init__(self, x_range, y_range, voxel_size: float, device):
+        import math
+
+        self.x_range, self.y_range, self.voxel = x_range, y_range, float(voxel_size)
+        self.nx = math.ceil((x_range[1] - x_range[0]) / voxel_size)
+        self.ny = math.ceil((y_range[1] - y_range[0]) / voxel_size)
+        self.min_bound = (math.ceil(x_range[0] / voxel_size), math.ceil(y_range[0] / voxel_size))
+        self.grid = torch.zeros((self.nx, self.ny), device=device, dtype=_F32)
+        self._stamps = torch.zeros(self.nx * self.ny, device=device, dtype=torch.int32)
+        self._n = 0
+
+    def add(self, points: torch.Tensor) -> None:
+        _req(points, "points")
+        if points.dim() != 2 or points.shape[1] < 2 or not points.is_contiguous():
+            raise ValueError("BevOccupancy.add: points must be contiguous [N, >=2]")
+        self._n += 1
+        with torch.cuda.device(points.device):
+            check(lib().lc_bev_occupancy_accumulate(
+                points.data_ptr(), points.shape[1], points.shape[0], float(self.x_range[0]),
+                float(self.x_range[1]), float(self.y_range[0]), float(self.y_range[1]), self.voxel,
+                self.min_bound[0], self.min_bound[1], self.nx, self.ny, self._n,
+                self._stamps.data_ptr(), self.grid.data_ptr(), _stream()),
+                "lc_bev_occupancy_accumulate")
+
+
+def sparse_quantize(coords: torch.Tensor, voxel_size=1.0, return_index: bool = False,
+                    return_inverse: bool = False):
+    """Device `sparse_quantize` (reference metric_utils.py:43-66): coords [N, 2|3] float32 ->
+    unique int32 voxels in ravel-hash order (+ first-occurrence indices, + inverse map, int64 like
+    np.unique).  One 8-byte device->host read for the number of unique voxels."""
+    _req(coords, "coords")
+    if coords.dim() != 2 or coords.shape[1] not in (2, 3) or not coords.is_contiguous():
+        raise ValueError("sparse_quantize: coords must be contiguous [N, 2] or [N, 3]")
+    N, D = coords.shape
+    vs = (float(voxel_size),) * D if isinstance(voxel_size, (int, float)) else tuple(map(float, voxel_size))
+    if len(vs) != D:
+        raise ValueError("sparse_quantize: voxel_size must have one entry per coordinate")
+    dev = coords.device
+    if N == 0:
+        outs = [torch.empty((0, D), device=dev, dtype=torch.int32)]
+        outs += [torch.empty(0, device=dev, dtype=torch.int64)] * (int(return_index) + int(return_inverse))
+        return outs[0] if len(outs) == 1 else outs
+    scratch = torch.empty(int(lib().lc_sparse_quantize_scratch_bytes(N, D)), device=dev, dtype=torch.uint8)
+    oc = torch.empty((N, D), device=dev, dtype=torch.int32)
+    oi = torch.empty(N, device=dev, dtype=torch.int64) if return_index else None
+    ov = torch.empty(N, device=dev, dtype=torch.int64) if return_inverse else None
+    cnt = torch.zeros(1, device=dev, dtype=torch.int64)
+    check(lib().lc_sparse_quantize(coords.data_ptr(), N, D, vs[0], vs[1], vs[2] if D == 3 else 1.0,
+                                   scratch.data_ptr(), oc.data_ptr(), _p(oi), _p(ov), cnt.data_ptr(),
+                                   _stream()), "lc_sparse_quantize")
+    n = int(cnt.item())
+    outs = [oc[:n]]
+    if return_index:
+        outs.append(oi[:n])
+    if return_inverse:
+        outs.append(ov)
+    return outs[0] if len(outs) == 1 else outs
+
+
 def rbf_kernel_mean(p: torch.Tensor, q: torch.Tensor, sigma: float = 0.5) -> torch.Tensor:
     """mean_ij exp(-|p_i - q_j|^2 / (2 sigma^2)) as a 0-d float64 device tensor (bev.py:27-34)."""
     _req(p, "p"), _req(q, "q")

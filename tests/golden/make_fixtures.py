@@ -481,6 +481,42 @@ def sec_object():
     save("object", **out)
 
 
+def sec_voxel():
+    """lidargen/metrics/metric_utils.py: ravel_hash :28-40, sparse_quantize :43-66, pcd2bev_sum
+    :233-258.  The module itself cannot be imported (its package __init__ pulls torchsparse and the
+    pretrained-extractor registry), so the three numpy-only functions are compiled from the file's
+    AST IN MEMORY (nothing of the source is stored) and run on seeded sweeps; the 1200 x 1200
+    volumes are stored sparsely (flat index + count)."""
+    import ast
+    import math
+    from itertools import repeat
+    from typing import List, Tuple, Union
+
+    src = open(R.REF + "/lidargen/metrics/metric_utils.py").read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef)
+            and n.name in ("ravel_hash", "sparse_quantize", "pcd2bev_sum")]
+    ns = dict(np=np, math=math, repeat=repeat, List=List, Tuple=Tuple, Union=Union, VOXEL_SIZE=0.05,
+              DATA_CONFIG={"64": {"x": [-50, 50], "y": [-50, 50], "z": [-3, 1]},
+                           "32": {"x": [-30, 30], "y": [-30, 30], "z": [-3, 6]}})
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "<metric_utils>", "exec"), ns)
+    out = {}
+    pts = synth_points(20000, seed=11)
+    for tag, cols, vs in (("2d", 2, 0.5), ("3d", 3, (0.4, 0.4, 0.2))):
+        c, idx, inv = ns["sparse_quantize"](pts[:, :cols], vs, return_index=True, return_inverse=True)
+        out[f"sq_{tag}_coords"], out[f"sq_{tag}_index"], out[f"sq_{tag}_inverse"] = c, idx, inv
+    out["hash"] = ns["ravel_hash"](np.floor(pts[:500, :3] / 0.7).astype(np.int32))
+    sets = [[synth_points(30000, seed=20 + 10 * k + i) for i in range(3)] for k in range(2)]
+    sets[0][0][:6, :2] = [[30.0, 0.0], [-30.0, 0.0], [29.999998, 1.0], [-29.999998, 1.0],
+                          [0.0, 29.999998], [0.025, 0.05]]                   # range edges, bin edges
+    vols = ns["pcd2bev_sum"]("32", sets[0], sets[1])
+    for k, v in enumerate(vols):
+        nz = np.flatnonzero(v)
+        out[f"bev{k}_idx"], out[f"bev{k}_cnt"] = nz.astype(np.int32), v.flat[nz].astype(np.uint8)
+        out[f"bev{k}_shape"] = np.array(v.shape)
+    save("voxel", **out)
+
+
 def synth_boxes(n, pts, seed):
     from lidarcrafter_amd.testing import synth_boxes as f
     return f(n, pts, seed)
