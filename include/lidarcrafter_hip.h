@@ -125,6 +125,35 @@ int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, co
  * this problem and tile configuration, 0 when the chosen kernel emits none (Co % 8 != 0, or the
  * 2-blocks/CU kernel): ask before allocating. */
 int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, int ks, int tile_cfg);
+/* PRE-SPLIT activations.  The f16x2 kernels need every conv input as fp16 hi + lo halves; instead of
+ * splitting the fp32 tile inside the conv's K loop (once per 64-output-channel block), the PRODUCER
+ * of the tensor -- the GroupNorm apply pass in front of almost every conv of the denoisers
+ * (efficient_unet.py:101-108, layout_unet_v1.py:171-175) -- can write the split form directly:
+ *   y_split: 16-byte units (8 fp16 channels of one pixel), [B][plane = hi, lo][C/8][H][W]
+ *            = lc_split_act_units(B, C, H, W) units, the same bytes as fp32 NCHW (needs C % 16 == 0
+ *            and whole octets per group: LC_EUNSUP otherwise -- use the fp32 forms then),
+ * already multiplied by the CONSUMER layer's x_scale (`range`, whose amax_scaled it maintains: the
+ * range-safety contract of lc_conv_range moves to the producer).  lc_conv2d_ring_f16x2_ps_fwd then
+ * stages its tiles with LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPRs, no VALU, no ds_write in
+ * the K loop.  3x3 ring convolution, pipelined tile shapes (tile_cfg 0 = auto, 12/13/15/22/23/25/28);
+ * wp_lo must be wp_hi + one plane (ONE allocation holding both planes of
+ * lc_pack_conv_weight_f16x2).  Everything else as lc_conv2d_ring_f16x2_fwd. */
+int64_t lc_split_act_units(int B, int C, int H, int W);
+int lc_groupnorm_apply_split(const float* x, int64_t x_bs, const double* partials, const float* gamma,
+                             const float* beta, const float* scale, const float* shift, int64_t ss_bs,
+                             void* y_split, int B, int C, int H, int W, int G, float eps, int act_silu,
+                             lc_conv_range* range, lc_stream_t s);
+int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const lc_oct_stats* s0,
+                                const lc_oct_stats* s1, const float* gamma, const float* beta,
+                                const float* scale, const float* shift, int64_t ss_bs, void* y_split,
+                                int B, int C, int H, int W, int G, float eps, int act_silu,
+                                lc_conv_range* range, lc_stream_t s);
+int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo,
+                                const float* bias, const float* res, int64_t res_bs, float* y,
+                                int64_t y_bs, int B, int Ci, int Co, int H, int W, float out_scale,
+                                int tile_cfg, float* gn_ostats_out, const float* wmeta,
+                                lc_conv_range* range, lc_stream_t s);
+
 /* Fused input normalisation: with gn_coeffs != NULL the kernel applies
  *   x <- silu?( (x - mu) * A + Bc )       rows (mu, A, Bc, 0) from lc_groupnorm_coeffs
  * while staging the input tile (the GN -> SiLU -> Conv chain of efficient_unet.py:101-108 and

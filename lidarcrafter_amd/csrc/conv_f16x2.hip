@@ -50,6 +50,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_ABLATE
 #define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
 #endif
+#ifndef LC_PS_ABL
+#define LC_PS_ABL 0   // pre-split kernel ablation: 1 no DMA in the K loop, 2 no MFMAs, 4 no x DMA, 8 no w DMA
+#endif
+#ifndef LC_PS_SCHED
+#define LC_PS_SCHED 0   // pre-split kernel: 0 = fence per tap (reads of tap t+1, then MFMAs of tap t), 1 = 1:1 interleave
+#endif
 #ifndef LC_F16X2_TERMS
 // which of the three products are accumulated: bit 0 wh*xh, bit 1 wl*xh, bit 2 wh*xl.  7 in the
 // product; 1 / 3 / 5 exist only to MEASURE what fewer passes cost in accuracy
@@ -67,6 +73,11 @@ struct ConvArgsH {
     float* y;
     lc_conv_range* range;     // x pre-scale of this layer + the running max of what was staged
     const float* wmeta;       // {w_scale, 1 / w_scale} written by lc_pack_conv_weight_f16x2
+    // pre-split input (conv_f16x2_ps_kernel): hi / lo fp16 planes written by the producer,
+    // half8 units [B][2][xsp_c8][H][W]; batch stride in units.  x is unused then.
+    const half8* xsp;
+    long long xsp_bs;
+    int xsp_c8;
     long long x_bs, res_bs, y_bs;
     int B, Ci, Co, H, W, Cib, Cop;
     int tiles_h, tiles_w;
@@ -846,6 +857,323 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     publish_amax(a.range, am, amax_seen);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// PRE-SPLIT INPUT variant: the activation arrives as two fp16 planes (hi, lo) in channel-octet
+// innermost layout  xsp[b][plane][c/8][h][w][8]  -- written by the PRODUCER (the GroupNorm apply
+// pass, lc_groupnorm_apply*_split: same 4 bytes per element as fp32 NCHW), already multiplied by
+// the layer's x_scale.  Staging is then a pure global -> LDS copy: every wave issues a handful of
+// `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per wave-instruction, no VGPRs, no ds_write, no
+// VALU) per K chunk for the x tile (ring / zero halo through per-lane source offsets and the
+// descriptor's out-of-range zero fill) and for the packed weights.  The K loop of a wave shrinks
+// from ~440 instructions per chunk (250 VALU of hi/lo split + selects, 38 loads, 10 ds_write) to
+// the 54 MFMAs, their 54 fragment reads and ~8 DMA issues.  Same block shapes, persistent tiles
+// and epilogue (bias / residual / scale / GroupNorm statistics of the output) as
+// conv_f16x2_pipe_kernel.  LDS image of a plane = unit index e = (cb, row, col) exactly as there,
+// padded to whole waves (the pad lanes read out of range -> zeros).
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (descriptor + per-lane voffset + uniform
+// soffset; out of range -> zeros) -> LDS at dst + 16 * lane.  (The builtin exists in the device
+// pass only; the host pass needs just the kernel's stub.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_vptr dst, unsigned voff,
+                                          unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <class C, bool EMIT_STATS>
+__global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvArgsH a) {
+    constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
+    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, WU = C::WU;
+    constexpr int KS = 2 * HALO + 1;
+    constexpr int NT = C::NT, NWV = NT / 64;
+    constexpr int NXI = (XU + 63) / 64, NWI = (WU + 63) / 64;     // DMA instructions per plane
+    constexpr int XS = NXI * 64, WS = NWI * 64;                   // units per plane in LDS
+    // DMA slots of a wave per chunk: slots [0, KX) move x (instruction wave + k * NWV of the 2 * NXI
+    // x instructions), slots [KX, KX + KW) move weights -- the KIND of a slot is static, so the
+    // issue code has no branch; a slot whose instruction index runs past the end reads out of
+    // range and lands in a 1 KiB dummy block behind the buffer.
+    constexpr int KX = (2 * NXI + NWV - 1) / NWV, KW = (2 * NWI + NWV - 1) / NWV;
+    constexpr int IPW = KX + KW;
+    constexpr int SPT = (IPW + NTAP - 1) / NTAP;                  // slots issued per tap (1 with 8 waves)
+    constexpr int BUF = 2 * XS + 2 * WS + 64;                     // + the dummy block
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ half8 lds[2 * BUF];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / C::WPX_, wpx = wave % C::WPX_;
+
+    const int tpb = a.tpb;
+    int bx = blockIdx.x;
+    if (a.xcd) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    int tw_i, th_i;
+    if (a.vert) {
+        const int gh_ = a.tiles_h / tpb;
+        tw_i = bx % a.tiles_w; bx /= a.tiles_w;
+        th_i = (bx % gh_) * tpb; bx /= gh_;
+    } else {
+        const int gw_ = a.tiles_w / tpb;
+        tw_i = (bx % gw_) * tpb; bx /= gw_;
+        th_i = bx % a.tiles_h; bx /= a.tiles_h;
+    }
+    const int b = bx;
+    int h0 = th_i * C::TH_, w0 = tw_i * C::TW_;
+    const int dh = a.vert ? C::TH_ : 0, dw = a.vert ? 0 : C::TW_;
+    const int co0 = blockIdx.y * BN;
+    const int H = a.H, W = a.W;
+    const int HW = H * W;
+    const int C8 = a.xsp_c8;
+    const float out_unscale = a.range->x_unscale * a.wmeta[1];
+
+    // descriptors: both planes of sample b; both weight planes (lo plane follows the hi plane)
+    const unsigned xbytes = 2u * (unsigned)C8 * (unsigned)HW * 16u;
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xsp + (long long)b * a.xsp_bs), 0, xbytes, 0x00020000);
+    const unsigned wplane = (unsigned)(NTAP * a.Cib) * (unsigned)a.Cop;       // units per weight plane
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, 2u * wplane * 16u,
+                                                                    0x00020000);
+
+    // per-lane source byte offsets (VGPR) and the LDS block of every slot (SGPR, units)
+    unsigned voff[IPW];
+    int ldsoff[IPW];
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+        if (k < KX) {
+            const int j = wave + k * NWV;
+            const int plane = j / NXI;
+            ldsoff[k] = j < 2 * NXI ? plane * XS + (j - plane * NXI) * 64 : 2 * XS + 2 * WS;
+        } else {
+            const int j = wave + (k - KX) * NWV;
+            const int plane = j / NWI;
+            ldsoff[k] = j < 2 * NWI ? 2 * XS + plane * WS + (j - plane * NWI) * 64 : 2 * XS + 2 * WS;
+        }
+    }
+    auto set_offsets = [&](int h0t, int w0t, bool weights_too) {
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) {
+            if (k < KX) {
+                const int j = wave + k * NWV;
+                const int plane = j / NXI, e = (j - plane * NXI) * 64 + lane;
+                const int cb = e / (XR * XW), rem = e - cb * (XR * XW);
+                const int r = rem / XW, c = rem - r * XW;
+                const int gh = h0t - HALO + r;
+                int gw = w0t - HALO + c;
+                gw %= W; if (gw < 0) gw += W;
+                const bool ok = j < 2 * NXI && e < XU && gh >= 0 && gh < H;
+                voff[k] = ok ? (unsigned)(((plane * C8 + cb) * H + gh) * W + gw) * 16u : OOB;
+            } else if (weights_too) {
+                const int j = wave + (k - KX) * NWV;
+                const int plane = j / NWI, e = (j - plane * NWI) * 64 + lane;
+                const int row = e / BN, cu = e - row * BN;
+                const int tap = row / CB, cb = row - tap * CB;
+                voff[k] = (j < 2 * NWI && e < WU)
+                              ? ((unsigned)((tap * a.Cib + cb) * a.Cop + co0 + cu) + plane * wplane) * 16u
+                              : OOB;
+            }
+        }
+    };
+    set_offsets(h0, w0, true);
+    const unsigned x_chunk = (unsigned)CB * (unsigned)HW * 16u;      // bytes between K chunks (x)
+    const unsigned w_chunk = (unsigned)CB * (unsigned)a.Cop * 16u;   // ... (weights)
+    auto issue_slot = [&](half8* buf, int k, unsigned xso, unsigned wso) {
+        if (LC_PS_ABL & 1) return;
+        if (k < KX) {
+            if (!(LC_PS_ABL & 4)) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], xso);
+        } else {
+            if (!(LC_PS_ABL & 8)) lds_dma16(rs_w, (lds_vptr)(buf + ldsoff[k]), voff[k], wso);
+        }
+    };
+    auto issue = [&](half8* buf, int ch) {
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) issue_slot(buf, k, (unsigned)ch * x_chunk, (unsigned)ch * w_chunk);
+    };
+
+    f32x16 acc[C::TCO_][C::TPX_];
+#pragma unroll
+    for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TPX_; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int kh = lane >> 5, l31 = lane & 31;
+    int xbase[C::TPX_];
+#pragma unroll
+    for (int j = 0; j < C::TPX_; ++j) {
+        const int t = wpx * C::TPX_ + j;
+        const int tr = t / C::TPR, tc = t - tr * C::TPR;
+        xbase[j] = kh * (XR * XW) + tr * XW + tc * 32 + l31;
+    }
+    const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
+
+    // One chunk of MFMAs from `cur`; the DMA of the NEXT chunk into `nxt` is issued one slot per tap
+    // inside the same stream, so that it lands in the shadow of the matrix pipe (all waves of a
+    // block run between the same barriers: whatever they do up front, they do it together and the
+    // pipe idles).
+    auto compute = [&](const half8* cur, half8* nxt, int nxt_ch) {
+        const unsigned xso = (unsigned)nxt_ch * x_chunk, wso = (unsigned)nxt_ch * w_chunk;
+        const half8* cxh = cur;
+        const half8* cxl = cur + XS;
+        const half8* cwh = cur + 2 * XS;
+        const half8* cwl = cwh + WS;
+        half8 ah[2][C::TCO_], al[2][C::TCO_], bh[2][C::TPX_], bl[2][C::TPX_];
+        auto fetch = [&](int tap, int s) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i) {
+                ah[s][i] = cwh[tap * CB * BN + wbase + i * 32];
+                al[s][i] = cwl[tap * CB * BN + wbase + i * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < C::TPX_; ++j) {
+                bh[s][j] = cxh[xbase[j] + dy * XW + dx];
+                bl[s][j] = cxl[xbase[j] + dy * XW + dx];
+            }
+        };
+        // The fragments of tap t+1 are requested BEFORE the MFMAs of tap t and consumed after them
+        // (two register sets): hipcc, left alone, sinks every ds_read next to its first use and
+        // exposes the LDS latency three times per tap (measured: waves parked 48 % of their
+        // lifetime) -- the scheduling fences pin the software pipeline.
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int s = tap & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+                if (tap * SPT + q < IPW) issue_slot(nxt, tap * SPT + q, xso, wso);
+            if (LC_PS_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+            if (LC_PS_SCHED == 1) {
+                // one fragment read in the shadow of each MFMA (mask 0x008 MFMA, 0x100 DS read)
+#pragma unroll
+                for (int q = 0; q < 3 * C::TCO_ * C::TPX_; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    half8* cur = lds;
+    half8* nxt = lds + BUF;
+    const int nchunk = a.Cib / CB;
+    const int last = nchunk - 1;
+    issue(cur, 0);
+    const int co_wave = co0 + wco * C::TCO_ * 32 + 4 * kh;
+    float bias_r[C::TCO_][16];
+#pragma unroll
+    for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+            bias_r[i][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
+        }
+    float res_r[C::TCO_][C::TPX_][16];
+    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    auto prefetch_res = [&]() {
+#pragma unroll
+        for (int j = 0; j < C::TPX_; ++j) {
+            const int t = wpx * C::TPX_ + j;
+            const int tr = t / C::TPR, tc = t - tr * C::TPR;
+            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+            const bool pok = gh < H && gw < W;
+            const long long poff = (long long)gh * W + gw;
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                    res_r[i][j][r] = (rb && pok && co < a.Co) ? rb[(long long)co * HW + poff] : 0.0f;
+                }
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto k_iter = [&](int nxt_ch) {
+        if (LC_PS_ABL & 2) issue(nxt, nxt_ch);
+        else compute(cur, nxt, nxt_ch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        half8* t = cur; cur = nxt; nxt = t;
+    };
+    float* yb = a.y + (long long)b * a.y_bs;
+    for (int tile = 0; tile < tpb; ++tile) {
+        for (int ch = 0; ch < last; ++ch) k_iter(ch + 1);
+        prefetch_res();
+        const bool more = tile + 1 < tpb;
+        if (more) set_offsets(h0 + dh, w0 + dw, false);
+        k_iter(more ? 0 : last);                   // chunk 0 of the next tile (or a harmless refill)
+        // ---- epilogue: as conv_f16x2_pipe_kernel --------------------------------------------
+        float st_p[C::TCO_][4], st_s[C::TCO_][4], st_q[C::TCO_][4];
+        int nvalid = 0;
+#pragma unroll
+        for (int j = 0; j < C::TPX_; ++j) {
+            const int t = wpx * C::TPX_ + j;
+            const int tr = t / C::TPR, tc = t - tr * C::TPR;
+            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+            const bool pok = gh < H && gw < W;
+            const long long poff = (long long)gh * W + gw;
+            if constexpr (EMIT_STATS) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
+                                    a.out_scale;
+                    if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
+                    if constexpr (EMIT_STATS) {
+                        const int m = r >> 2;
+                        if (j == 0 && (r & 3) == 0) {
+                            st_p[i][m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
+                            st_s[i][m] = 0.f; st_q[i][m] = 0.f;
+                        }
+                        const float d = pok ? v - st_p[i][m] : 0.0f;
+                        st_s[i][m] += d;
+                        st_q[i][m] = fmaf(d, d, st_q[i][m]);
+                    }
+                    acc[i][j][r] = 0.0f;
+                }
+            }
+        }
+        if constexpr (EMIT_STATS) {
+            const int slot = ((h0 / C::TH_) * a.tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
+            const int co_blk = co0 + wco * C::TCO_ * 32;
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int co_oct = co_blk + i * 32 + 8 * m;
+                    const float s_ = wave_sum_to_lane63(st_s[i][m]);
+                    const float q_ = wave_sum_to_lane63(st_q[i][m]);
+                    if (lane == 63 && co_oct < a.Co)
+                        a.ostats[((long long)b * (a.Co >> 3) + (co_oct >> 3)) * a.oslots + slot] =
+                            f32x4{st_p[i][m], (float)(8 * nvalid), s_, q_};
+                }
+            }
+        }
+        h0 += dh; w0 += dw;
+    }
+}
+
 template <class C>
 int launch_pipe(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
@@ -875,6 +1203,15 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     dim3 grid(a.B * a.tiles_h * a.tiles_w / tpb, ncot);
     a.xcd = (xcd_env && grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
 
+    if (a.xsp) {
+        if constexpr (C::NTAP == 9) {
+            if (a.ostats) hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
+            else hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
+            return lc_launch_status();
+        } else {
+            return LC_EUNSUP;
+        }
+    }
     if (a.ostats) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
     else hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
     return lc_launch_status();
@@ -1033,6 +1370,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.x = x; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
     a.y = y; a.x_bs = x_bs; a.res_bs = res_bs; a.y_bs = y_bs;
     a.range = range; a.wmeta = wmeta;
+    a.xsp = nullptr; a.xsp_bs = 0; a.xsp_c8 = 0;
     a.B = B; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W;
     a.Cib = (Ci + 15) / 16 * 2; a.Cop = (Co + 63) / 64 * 64;
     a.out_scale = out_scale;
@@ -1086,4 +1424,43 @@ extern "C" int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H
     if (ks == 1 && ((long long)H * W) % 128 == 0) { H = (int)(((long long)H * W) / 64); W = 64; }
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
     return pipe_stat_slots(tile_cfg, H, W);
+}
+
+// Pre-split input: see conv_f16x2_ps_kernel.  3x3 ring convolution only.
+extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo,
+                                           const float* bias, const float* res, int64_t res_bs,
+                                           float* y, int64_t y_bs, int B, int Ci, int Co, int H, int W,
+                                           float out_scale, int tile_cfg, float* gn_ostats_out,
+                                           const float* wmeta, lc_conv_range* range, lc_stream_t s) {
+    if (!x_split || !wp_hi || !wp_lo || !y || !wmeta || !range || B <= 0 || Ci <= 0 || Co <= 0 ||
+        H <= 0 || W <= 0)
+        return LC_EINVAL;
+    if (Ci % 16) return LC_EUNSUP;
+    if ((long long)H * W >= (1 << 24) || (long long)2 * (Ci / 8) * H * W * 16 >= (1ll << 31)) return LC_EUNSUP;
+    ConvArgsH a;
+    a.x = nullptr; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
+    a.y = y; a.x_bs = 0; a.res_bs = res_bs; a.y_bs = y_bs;
+    a.range = range; a.wmeta = wmeta;
+    a.B = B; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W;
+    a.Cib = Ci / 8; a.Cop = (Co + 63) / 64 * 64;
+    // the kernel addresses the lo plane as hi + one plane: the two must be one allocation
+    if (a.wl != a.wh + (long long)9 * a.Cib * a.Cop) return LC_EINVAL;
+    a.xsp = (const half8*)x_split; a.xsp_c8 = Ci / 8; a.xsp_bs = (long long)2 * (Ci / 8) * H * W;
+    a.out_scale = out_scale;
+    a.tiles_h = a.tiles_w = 0;
+    a.gn = nullptr; a.Cgn = 0; a.gn_silu = 0;
+    a.gs = lc_gn_stats_input{nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    a.seg[0] = a.seg[1] = ConvArgsH::OctSeg{nullptr, 0, 0};
+    a.tpb = 0;
+    if (tile_cfg >= 100) { a.tpb = tile_cfg / 100; tile_cfg %= 100; }
+    // (the pipelined tile shapes only: the heuristic's Ci >= 24 branch)
+    if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci < 24 ? 24 : Ci, Co, H, W, 3);
+    if (pipe_stat_slots(tile_cfg, H, W) <= 0) return LC_EUNSUP;
+    a.ostats = nullptr; a.oslots = 0;
+    if (gn_ostats_out) {
+        a.oslots = pipe_stat_slots(tile_cfg, H, W);
+        if (Co % 8) return LC_EUNSUP;
+        a.ostats = reinterpret_cast<f32x4*>(gn_ostats_out);
+    }
+    return dispatch_h<3>(tile_cfg, a, lc_s(s));
 }

@@ -220,6 +220,125 @@ __global__ __launch_bounds__(256) void gn_apply_os_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// GroupNorm apply with PRE-SPLIT output for conv_f16x2_ps_kernel: the same normalisation
+// (two-pass partials, OS = false, or the producer's octet statistics, OS = true), but every thread
+// owns ONE pixel of ONE channel octet: 8 channel loads (coalesced across the wave along W), the
+// affine / AdaGN / SiLU arithmetic of gn_apply_kernel, multiplication by the consumer layer's
+// x_scale, the fp16 hi/lo split of conv_f16x2.hip (split rule restated: hi = 11 significant bits
+// truncated, packed toward zero; lo = fp16(s - hi)) and two 16-byte stores into
+// ysp[b][plane][c/8][h][w][8].  max |y * x_scale| goes to the consumer's lc_conv_range.  The split
+// therefore runs ONCE per element in a memory-bound kernel instead of once per output-channel
+// block inside the conv's K loop.  Needs C % 16 == 0 and whole octets per group.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+template <bool OS>
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(
+    const float* __restrict__ x, long long x_bs, const double* __restrict__ part, OctStats2 os,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+    const float* __restrict__ shift, long long ss_bs, half8_t* __restrict__ ysp, long long ysp_bs,
+    int C, int G, long long HW, int nch, float eps, int act, lc_conv_range* range) {
+    __shared__ double sh[12];
+    const int oct = blockIdx.y, b = blockIdx.z;
+    const int c0 = oct * 8, cpg = C / G, g = c0 / cpg;
+    float mu, rstd;
+    if constexpr (!OS) {
+        const double* pp = part + ((long long)b * G + g) * nch * 2;
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < nch; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
+        const double n = (double)cpg * (double)HW;
+        const double dm = s / n;
+        double var = q / n - dm * dm;
+        if (var < 0.0) var = 0.0;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+        mu = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
+    } else {
+        const int cg0 = g * cpg;
+        const bool seg1 = cg0 >= os.c0;
+        const int slots = seg1 ? os.slots1 : os.slots0;
+        const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> 3) + ((cg0 - os.c0) >> 3)) * slots
+                              : os.p0 + ((long long)b * (os.c0 >> 3) + (cg0 >> 3)) * slots;
+        const int n_ent = (cpg >> 3) * slots;
+        const double P0 = (double)e[0].x;
+        double N = 0.0, S = 0.0, Q = 0.0;
+        for (int base = threadIdx.x; base < n_ent; base += 256 * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = base + 256 * k < n_ent ? e[base + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double n = v[k].y, d = (double)v[k].x - P0, s_ = v[k].z;
+                N += n;
+                S += s_ + n * d;
+                Q += (double)v[k].w + d * (2.0 * s_ + n * d);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            N += __shfl_xor(N, o, 64); S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sh[3 * wv] = N; sh[3 * wv + 1] = S; sh[3 * wv + 2] = Q; }
+        __syncthreads();
+        N = (sh[0] + sh[3]) + (sh[6] + sh[9]);
+        S = (sh[1] + sh[4]) + (sh[7] + sh[10]);
+        Q = (sh[2] + sh[5]) + (sh[8] + sh[11]);
+        const double m = N > 0.0 ? S / N : 0.0;
+        double var = N > 0.0 ? Q / N - m * m : 0.0;
+        if (var < 0.0) var = 0.0;
+        mu = (float)(P0 + m);
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    float ga[8], be[8], sc[8], sf[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        ga[k] = gamma ? gamma[c] : 1.0f; be[k] = beta ? beta[c] : 0.0f;
+        sc[k] = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+        sf[k] = shift ? shift[b * ss_bs + c] : 0.0f;
+    }
+    const float xs = range->x_scale;
+    const float seen = range->amax_scaled;
+    float am = 0.0f;
+    const int C8 = C >> 3;
+    const float* xp = x + b * x_bs + (long long)c0 * HW;
+    half8_t* yh = ysp + b * ysp_bs + (long long)oct * HW;
+    half8_t* yl = yh + (long long)C8 * HW;
+    const long long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per;
+    const long long hi = lo + per < HW ? lo + per : HW;
+    for (long long p = lo + threadIdx.x; p < hi; p += 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = xp[(long long)k * HW + p];
+        half8_t h8, l8;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            float t0 = (v[k] - mu) * rstd, t1 = (v[k + 1] - mu) * rstd;
+            t0 = t0 * ga[k] + be[k];         t1 = t1 * ga[k + 1] + be[k + 1];
+            t0 = t0 * sc[k] + sf[k];         t1 = t1 * sc[k + 1] + sf[k + 1];
+            if (act) { t0 = lc_silu(t0); t1 = lc_silu(t1); }
+            const float s0 = t0 * xs, s1 = t1 * xs;
+            am = fmaxf(am, fmaxf(fabsf(s0), fabsf(s1)));
+            const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+            const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+            const half2_t ph = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+            float2_t r; r.x = s0 - h0; r.y = s1 - h1;
+            const half2_t pl = __builtin_convertvector(r, half2_t);
+            h8[k] = ph.x; h8[k + 1] = ph.y; l8[k] = pl.x; l8[k + 1] = pl.y;
+        }
+        yh[p] = h8;
+        yl[p] = l8;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0 && am > seen)
+        atomicMax(reinterpret_cast<unsigned*>(&range->amax_scaled), __float_as_uint(am));
+}
+
 }  // namespace
 
 extern "C" int lc_groupnorm_coeffs(const float* x, int64_t x_bs, const double* partials,
@@ -305,5 +424,61 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
     hipLaunchKernelGGL(gn_apply_os_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
                        (long long)x_bs, os, gamma, beta, scale, shift, (long long)ss_bs, y,
                        (long long)y_bs, C, G, HW, eps, act_silu, cpb);
+    return lc_launch_status();
+}
+
+// ---- pre-split output (see gn_apply_split_kernel) -------------------------------------------------
+static int split_slabs(int B, int C, long long HW) {
+    int slabs = (int)((HW + 2047) / 2048);                 // >= 2048 pixels (x 8 channels) per block
+    if (slabs < 1) slabs = 1;
+    while (slabs > 1 && (long long)B * (C / 8) * slabs > 8192) slabs = (slabs + 1) / 2;
+    return slabs;
+}
+
+extern "C" int64_t lc_split_act_units(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)B * 2 * ((C + 15) / 16 * 2) * H * W;    // 16-byte units
+}
+
+extern "C" int lc_groupnorm_apply_split(const float* x, int64_t x_bs, const double* partials,
+                                        const float* gamma, const float* beta, const float* scale,
+                                        const float* shift, int64_t ss_bs, void* y_split, int B, int C,
+                                        int H, int W, int G, float eps, int act_silu,
+                                        lc_conv_range* range, lc_stream_t s) {
+    if (!x || !y_split || !partials || !range || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
+    if (C % 16 || (C / G) % 8) return LC_EUNSUP;
+    const long long HW = (long long)H * W;
+    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
+    OctStats2 os{nullptr, nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(gn_apply_split_kernel<false>, dim3(split_slabs(B, C, HW), C / 8, B), dim3(256), 0,
+                       lc_s(s), x, (long long)x_bs, partials, os, gamma, beta, scale, shift,
+                       (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
+                       (long long)2 * (C / 8) * HW, C, G, HW, nch, eps, act_silu, range);
+    return lc_launch_status();
+}
+
+extern "C" int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const lc_oct_stats* s0,
+                                           const lc_oct_stats* s1, const float* gamma,
+                                           const float* beta, const float* scale, const float* shift,
+                                           int64_t ss_bs, void* y_split, int B, int C, int H, int W,
+                                           int G, float eps, int act_silu, lc_conv_range* range,
+                                           lc_stream_t s) {
+    if (!x || !y_split || !range || B <= 0 || G <= 0 || C % G || !s0 || !s0->p || s0->channels <= 0 ||
+        s0->slots <= 0)
+        return LC_EINVAL;
+    OctStats2 os;
+    os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
+    os.p1 = nullptr; os.c1 = 0; os.slots1 = 0;
+    if (s1) {
+        if (!s1->p || s1->channels <= 0 || s1->slots <= 0) return LC_EINVAL;
+        os.p1 = reinterpret_cast<const f32x4*>(s1->p); os.c1 = s1->channels; os.slots1 = s1->slots;
+    }
+    const int cpg = C / G;
+    if (os.c0 + os.c1 != C || cpg % 8 || os.c0 % cpg || os.c0 % 8 || os.c1 % 8 || C % 16) return LC_EUNSUP;
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(gn_apply_split_kernel<true>, dim3(split_slabs(B, C, HW), C / 8, B), dim3(256), 0,
+                       lc_s(s), x, (long long)x_bs, nullptr, os, gamma, beta, scale, shift,
+                       (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
+                       (long long)2 * (C / 8) * HW, C, G, HW, 0, eps, act_silu, range);
     return lc_launch_status();
 }

@@ -110,13 +110,15 @@ class ResidualBlock(nn.Module):
                               emit_stats=True)
         # unfused GroupNorms (wide layers): the producing convs leave the statistics, the
         # GroupNorm is a single apply pass
-        a = self.norm1(x, act_silu=True)
+        # (where the shape allows, the apply pass writes its result pre-split for the conv that
+        #  consumes it -- hi / lo fp16 planes staged by LDS-DMA, ops.groupnorm `split_for`)
+        a = self.norm1(x, act_silu=True, split_for=self.conv1._packed)
         h = self.conv1(a, emit_stats=True)
         if self.has_emb:
-            a = self.norm2(h, emb, scale_shift=scale_shift, act_silu=True, out=a
-                           if a.shape == h.shape else None)
+            a = self.norm2(h, emb, scale_shift=scale_shift, act_silu=True,
+                           split_for=self.conv2._packed)
         else:
-            a = self.norm2(h, act_silu=True)
+            a = self.norm2(h, act_silu=True, split_for=self.conv2._packed)
         sk = x if isinstance(self.skip, nn.Identity) else self.skip(x, out=h)
         return self.conv2(a, res=sk, out=out, out_scale=self._scale_f, emit_stats=True)
 

@@ -96,9 +96,11 @@ class Resample(nn.Module):
 class GroupNorm(nn.GroupNorm):
     """nn.GroupNorm with an optional fused SiLU (GN -> SiLU is one kernel pair here)."""
 
-    def forward(self, x, act_silu: bool = False, out=None):
+    def forward(self, x, act_silu: bool = False, out=None, split_for=None):
+        """split_for: the `_packed` of the 3x3 conv that consumes the result (pre-split output,
+        ops.groupnorm)."""
         return K.groupnorm(x, self.num_groups, self.eps, self.weight, self.bias,
-                           act_silu=act_silu, out=out)
+                           act_silu=act_silu, out=out, split_for=split_for)
 
     def coeffs(self, x):
         """Statistics only: the next conv derives the per-(b, channel) rows in its prologue and
@@ -117,10 +119,11 @@ class AdaGN(nn.GroupNorm):
         C = self.num_channels
         return ss[:, :C], ss[:, C:]
 
-    def forward(self, x, emb=None, scale_shift=None, act_silu: bool = False, out=None):
+    def forward(self, x, emb=None, scale_shift=None, act_silu: bool = False, out=None,
+                split_for=None):
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
         return K.groupnorm(x, self.num_groups, self.eps, None, None, scale, shift,
-                           act_silu=act_silu, out=out)
+                           act_silu=act_silu, out=out, split_for=split_for)
 
     def coeffs(self, x, emb=None, scale_shift=None):
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)

@@ -466,6 +466,35 @@ def range_checked(forward):
     return wrapper
 
 
+# Pre-split activations (conv_f16x2_ps_kernel): the GroupNorm apply pass in front of a 3x3 conv
+# writes fp16 hi / lo planes [B][2][C/8][H][W][8] (already multiplied by the consumer's x_scale)
+# and the conv stages them with LDS-DMA.  LC_PRESPLIT=0 keeps the fp32 route everywhere.
+PRESPLIT = _os.environ.get("LC_PRESPLIT", "1") != "0"
+
+
+class SplitAct:
+    """A [B, C, H, W] activation in the pre-split form, produced for ONE consumer conv (`packed`:
+    the layer whose x_scale it carries).  Not a tensor: only `conv2d_ring` consumes it."""
+
+    __slots__ = ("buf", "shape", "packed")
+
+    def __init__(self, buf, shape, packed):
+        self.buf, self.shape, self.packed = buf, tuple(shape), packed
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @property
+    def is_cuda(self):
+        return self.buf.is_cuda
+
+
+def can_presplit(C: int, G: int) -> bool:
+    return PRESPLIT and CONV_PRECISION == "f16x2" and C % 16 == 0 and G > 0 and C % G == 0 and \
+        (C // G) % 8 == 0
+
+
 class PackedConv:
     """Packed copies of an OIHW conv weight for the MFMA kernels (fp32 wp[tap][Ci^8][Co^64] and/or
     the f16x2 hi/lo planes + their device-derived pre-scale), rebuilt when the parameter changes;
@@ -528,8 +557,8 @@ class PackedConv:
         self._refresh(weight)
         if self.wh is None:
             n = lib().lc_packed_conv_weight_f16x2_elems(self.Co, self.Ci, self.ks)
-            self.wh = torch.empty(n, device=weight.device, dtype=torch.float16)
-            self.wl = torch.empty(n, device=weight.device, dtype=torch.float16)
+            both = torch.empty(2 * n, device=weight.device, dtype=torch.float16)
+            self.wh, self.wl = both[:n], both[n:]      # ONE allocation: the LDS-DMA kernel addresses
             self.wmeta = torch.empty(4, device=weight.device, dtype=_F32)
             check(lib().lc_pack_conv_weight_f16x2(self._w4.data_ptr(), self.wh.data_ptr(),
                                                   self.wl.data_ptr(), self.Co, self.Ci, self.ks,
@@ -554,6 +583,9 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     this module that writes into an `out=` tensor forgets the statistics of what it overwrites;
     a caller who modifies such a tensor with a torch in-place op must not request them (inference
     tensors carry no version counter that could catch it)."""
+    if isinstance(x, SplitAct):
+        return _conv2d_ring_presplit(x, packed, weight, bias, res, out, out_scale, tile_cfg,
+                                     emit_stats)
     x_bs = _bs4(x, "x")
     prec = precision or CONV_PRECISION
     if gn_coeffs is not None and prec != "f16x2":
@@ -616,6 +648,48 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     return out
 
 
+def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, out, out_scale,
+                          tile_cfg, emit_stats) -> torch.Tensor:
+    """3x3 ring conv of a pre-split activation (lc_conv2d_ring_f16x2_ps_fwd, LDS-DMA staging)."""
+    if xs.packed is not packed:
+        raise ValueError("conv: the pre-split activation was produced for another layer "
+                         "(its x_scale belongs to that layer's range record)")
+    wh, wl = packed.get_f16x2(weight)
+    B, Ci, H, W = xs.shape
+    if Ci != packed.Ci or packed.ks != 3:
+        raise ValueError("conv: pre-split input needs a 3x3 kernel with matching channels")
+    Co = packed.Co
+    dev = xs.buf.device
+    if out is None:
+        out = torch.empty((B, Co, H, W), device=dev, dtype=_F32)
+    y_bs = _bs4(out, "out")
+    if tuple(out.shape) != (B, Co, H, W):
+        raise ValueError(f"conv: out shape {tuple(out.shape)} != {(B, Co, H, W)}")
+    r_bs = 0
+    if res is not None:
+        r_bs = _bs4(res, "res")
+        if tuple(res.shape) != (B, Co, H, W):
+            raise ValueError("conv: residual shape mismatch")
+    if bias is not None:
+        _req(bias, "bias")
+    _drop_stats(out)
+    with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9):
+        sbuf, slots = None, 0
+        if emit_stats and PRODUCER_GN_STATS:
+            slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, max(Ci, 24), Co, H, W, 3,
+                                                               int(tile_cfg)))
+            if slots > 0:
+                sbuf = torch.empty((B, Co // 8, slots, 4), device=dev, dtype=_F32)
+        check(lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+                                                _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B, Ci,
+                                                Co, H, W, float(out_scale), int(tile_cfg), _p(sbuf),
+                                                packed.wmeta.data_ptr(), packed.range_ptr(dev),
+                                                _stream()), "lc_conv2d_ring_f16x2_ps_fwd")
+        if sbuf is not None:
+            _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H, W)))
+    return out
+
+
 # ------------------------------------------------------------------------------------ norm
 _gn_scratch = {}
 
@@ -630,13 +704,19 @@ def _partials(dev, n: int) -> torch.Tensor:
 
 
 def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=None, shift=None,
-              act_silu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              act_silu: bool = False, out: Optional[torch.Tensor] = None,
+              split_for: Optional["PackedConv"] = None):
     """GroupNorm (+affine) (+ (1+scale)*h+shift) (+SiLU).  scale/shift: [B, C] views (row stride
-    may exceed C, e.g. the two halves of one [B, 2C] AdaGN projection)."""
+    may exceed C, e.g. the two halves of one [B, 2C] AdaGN projection).
+    split_for: the PackedConv of the 3x3 conv that consumes the result -- when the shape allows
+    (`can_presplit`) the result is written PRE-SPLIT for that layer and returned as a `SplitAct`
+    (same bytes, no fp32 copy exists); otherwise a plain fp32 tensor comes back."""
     x_bs = _bs4(x, "x")
     B, C, H, W = x.shape
     if C % G:
         raise ValueError(f"groupnorm: C={C} not divisible by G={G}")
+    if split_for is not None and out is None and can_presplit(C, G):
+        return _groupnorm_split(x, x_bs, G, eps, gamma, beta, scale, shift, act_silu, split_for)
     if out is None:
         out = torch.empty((B, C, H, W), device=x.device, dtype=_F32)
     y_bs = _bs4(out, "out")
@@ -671,6 +751,44 @@ def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=
                                        _p(scale), _p(shift), ss_bs, out.data_ptr(), y_bs, B, C, H,
                                        W, G, float(eps), int(act_silu), st), "lc_groupnorm_apply")
     return out
+
+
+def _groupnorm_split(x, x_bs, G, eps, gamma, beta, scale, shift, act_silu, packed) -> SplitAct:
+    import ctypes as C_
+
+    from ._lib import OctStats
+
+    B, C, H, W = x.shape
+    ss_bs = 0
+    if scale is not None:
+        _req(scale, "scale"), _req(shift, "shift")
+        if scale.shape != (B, C) or shift.shape != (B, C) or scale.stride(1) != 1 or \
+                shift.stride(1) != 1 or scale.stride(0) != shift.stride(0):
+            raise ValueError("groupnorm: scale/shift must be [B,C] with unit inner stride")
+        ss_bs = scale.stride(0)
+    units = int(lib().lc_split_act_units(B, C, H, W))
+    buf = torch.empty((units, 8), device=x.device, dtype=torch.float16)
+    rng_ptr = packed.range_ptr(x.device)
+    st = _stream()
+    hs = _find_stats(x, G)
+    if hs is not None:
+        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots) for h in hs]
+        with _Timed("groupnorm", 8.0 * B * C * H * W):
+            check(lib().lc_groupnorm_apply_os_split(
+                x.data_ptr(), x_bs, C_.byref(keep[0]), C_.byref(keep[1]) if len(keep) > 1 else None,
+                _p(gamma), _p(beta), _p(scale), _p(shift), ss_bs, buf.data_ptr(), B, C, H, W, G,
+                float(eps), int(act_silu), rng_ptr, st), "lc_groupnorm_apply_os_split")
+    else:
+        n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
+        part = _partials(x.device, n)
+        with _Timed("groupnorm", 12.0 * B * C * H * W):
+            check(lib().lc_groupnorm_stats(x.data_ptr(), x_bs, part.data_ptr(), B, C, H, W, G, st),
+                  "lc_groupnorm_stats")
+            check(lib().lc_groupnorm_apply_split(
+                x.data_ptr(), x_bs, part.data_ptr(), _p(gamma), _p(beta), _p(scale), _p(shift), ss_bs,
+                buf.data_ptr(), B, C, H, W, G, float(eps), int(act_silu), rng_ptr, st),
+                "lc_groupnorm_apply_split")
+    return SplitAct(buf, (B, C, H, W), packed)
 
 
 class GnStats:
@@ -1276,7 +1394,7 @@ def _wrap_public_ops():
 
     g = globals()
     skip = {"fuse_gn", "set_conv_precision", "range_poll", "range_checked", "defer_range_checks",
-            "name_packed_convs", "rng_snapshot", "rng_restore", "run_range_safe"}
+            "name_packed_convs", "rng_snapshot", "rng_restore", "run_range_safe", "can_presplit"}
     for name, obj in list(g.items()):
         if isinstance(obj, types.FunctionType) and not name.startswith("_") and name not in skip \
                 and obj.__module__ == __name__ and not getattr(obj, "_lc_entry", False):
