@@ -151,8 +151,19 @@ int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const lc_oct_stats
 int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo,
                                 const float* bias, const float* res, int64_t res_bs, float* y,
                                 int64_t y_bs, int B, int Ci, int Co, int H, int W, float out_scale,
-                                int tile_cfg, float* gn_ostats_out, const float* wmeta,
-                                lc_conv_range* range, lc_stream_t s);
+                                int tile_cfg, float* gn_ostats_out,
+                                float* splitk_part /* NULL, or [ksplit, B, Co, H, W] */, int ksplit,
+                                const float* wmeta, lc_conv_range* range, lc_stream_t s);
+/* SPLIT-K for small grids (batch 1-2 at the deep levels: 16-64 blocks on 256 CUs): with splitk_part
+ * != NULL the conv launches ksplit (2 ... Ci/16) blocks per tile, each over a contiguous range of
+ * the K chunks, and stores raw partial sums only (bias / res / out_scale / statistics are ignored);
+ * lc_splitk_reduce sums the planes in index order (deterministic) and applies the epilogue, with
+ * optional GroupNorm statistics of the result in the conv epilogue's entry format
+ * (lc_splitk_stats_slots(H, W) entries per (sample, octet)). */
+int64_t lc_splitk_stats_slots(int H, int W);
+int lc_splitk_reduce(const float* part, int ksplit, const float* bias, const float* res,
+                     int64_t res_bs, float* y, int64_t y_bs, int B, int Co, int H, int W,
+                     float out_scale, float* gn_ostats_out, lc_stream_t s);
 
 /* Fused input normalisation: with gn_coeffs != NULL the kernel applies
  *   x <- silu?( (x - mu) * A + Bc )       rows (mu, A, Bc, 0) from lc_groupnorm_coeffs

@@ -58,7 +58,9 @@ SIGNATURES = {
     "lc_groupnorm_apply_os_split": (i32, [vp, i64, _os, _os, vp, vp, vp, vp, i64, vp, i32, i32, i32,
                                           i32, i32, f32, i32, vp, vp]),
     "lc_conv2d_ring_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32,
-                                          f32, i32, vp, vp, vp, vp]),
+                                          f32, i32, vp, vp, i32, vp, vp, vp]),
+    "lc_splitk_stats_slots": (i64, [i32, i32]),
+    "lc_splitk_reduce": (i32, [vp, i32, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, vp, vp]),
     "lc_conv2d_ring_f16x2_stats_slots": (i64, [i32, i32, i32, i32, i32, i32, i32]),
     "lc_groupnorm_coeffs": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                   i32, f32, vp]),

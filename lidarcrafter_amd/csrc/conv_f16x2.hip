@@ -53,6 +53,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_PS_ABL
 #define LC_PS_ABL 0   // pre-split kernel ablation: 1 no DMA in the K loop, 2 no MFMAs, 4 no x DMA, 8 no w DMA
 #endif
+#ifndef LC_EMIT_ABL
+#define LC_EMIT_ABL 0   // pre-split kernel, statistics epilogue ablation: 1 no per-element sums, 2 no reductions / stores
+#endif
 #ifndef LC_PS_SCHED
 #define LC_PS_SCHED 0   // pre-split kernel: 0 = fence per tap (reads of tap t+1, then MFMAs of tap t), 1 = 1:1 interleave
 #endif
@@ -78,6 +81,10 @@ struct ConvArgsH {
     const half8* xsp;
     long long xsp_bs;
     int xsp_c8;
+    // split-K (pre-split kernel, small grids): blockIdx.z owns a contiguous range of the K chunks
+    // and stores its raw partial sums to part[z][b][co][h][w]; lc_splitk_reduce finishes
+    float* part;
+    int ksplit;
     long long x_bs, res_bs, y_bs;
     int B, Ci, Co, H, W, Cib, Cop;
     int tiles_h, tiles_w;
@@ -1075,8 +1082,11 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
     half8* cur = lds;
     half8* nxt = lds + BUF;
     const int nchunk = a.Cib / CB;
-    const int last = nchunk - 1;
-    issue(cur, 0);
+    // split-K: this block's chunk range [ch_lo, ch_hi)
+    const int ksp = a.part ? a.ksplit : 1;
+    const int ch_lo = (int)blockIdx.z * nchunk / ksp, ch_hi = ((int)blockIdx.z + 1) * nchunk / ksp;
+    const int last = ch_hi - 1;
+    issue(cur, ch_lo);
     const int co_wave = co0 + wco * C::TCO_ * 32 + 4 * kh;
     float bias_r[C::TCO_][16];
 #pragma unroll
@@ -1116,11 +1126,32 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
     };
     float* yb = a.y + (long long)b * a.y_bs;
     for (int tile = 0; tile < tpb; ++tile) {
-        for (int ch = 0; ch < last; ++ch) k_iter(ch + 1);
-        prefetch_res();
+        for (int ch = ch_lo; ch < last; ++ch) k_iter(ch + 1);
+        if (!a.part) prefetch_res();
         const bool more = tile + 1 < tpb;
         if (more) set_offsets(h0 + dh, w0 + dw, false);
-        k_iter(more ? 0 : last);                   // chunk 0 of the next tile (or a harmless refill)
+        k_iter(more ? ch_lo : last);               // first chunk of the next tile (or a harmless refill)
+        if (a.part) {                              // split-K: raw partial sums, finished by the reduce pass
+            float* pb = a.part + ((long long)blockIdx.z * a.B + b) * a.Co * HW;
+#pragma unroll
+            for (int j = 0; j < C::TPX_; ++j) {
+                const int t = wpx * C::TPX_ + j;
+                const int tr = t / C::TPR, tc = t - tr * C::TPR;
+                const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+                const bool pok = gh < H && gw < W;
+                const long long poff = (long long)gh * W + gw;
+#pragma unroll
+                for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (pok && co < a.Co) epi_store(&pb[(long long)co * HW + poff], acc[i][j][r] * out_unscale);
+                        acc[i][j][r] = 0.0f;
+                    }
+            }
+            h0 += dh; w0 += dw;
+            continue;
+        }
         // ---- epilogue: as conv_f16x2_pipe_kernel --------------------------------------------
         float st_p[C::TCO_][4], st_s[C::TCO_][4], st_q[C::TCO_][4];
         int nvalid = 0;
@@ -1140,7 +1171,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                     const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
                                     a.out_scale;
                     if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
-                    if constexpr (EMIT_STATS) {
+                    if constexpr (EMIT_STATS && !(LC_EMIT_ABL & 1)) {
                         const int m = r >> 2;
                         if (j == 0 && (r & 3) == 0) {
                             st_p[i][m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
@@ -1154,7 +1185,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                 }
             }
         }
-        if constexpr (EMIT_STATS) {
+        if constexpr (EMIT_STATS && !(LC_EMIT_ABL & 2)) {
             const int slot = ((h0 / C::TH_) * a.tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
             const int co_blk = co0 + wco * C::TCO_ * 32;
 #pragma unroll
@@ -1198,6 +1229,7 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
         vert = vert_env && a.tiles_h % tpb == 0;
         if (!vert && a.tiles_w % tpb) tpb = 1;
     }
+    if (a.part) tpb = 1;                                 // split-K blocks own one tile
     a.tpb = tpb;
     a.vert = vert;
     dim3 grid(a.B * a.tiles_h * a.tiles_w / tpb, ncot);
@@ -1205,7 +1237,8 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
 
     if (a.xsp) {
         if constexpr (C::NTAP == 9) {
-            if (a.ostats) hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
+            if (a.part) grid.z = a.ksplit;
+            if (a.ostats && !a.part) hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
             else hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
             return lc_launch_status();
         } else {
@@ -1370,7 +1403,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.x = x; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
     a.y = y; a.x_bs = x_bs; a.res_bs = res_bs; a.y_bs = y_bs;
     a.range = range; a.wmeta = wmeta;
-    a.xsp = nullptr; a.xsp_bs = 0; a.xsp_c8 = 0;
+    a.xsp = nullptr; a.xsp_bs = 0; a.xsp_c8 = 0; a.part = nullptr; a.ksplit = 0;
     a.B = B; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W;
     a.Cib = (Ci + 15) / 16 * 2; a.Cop = (Co + 63) / 64 * 64;
     a.out_scale = out_scale;
@@ -1431,11 +1464,13 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
                                            const float* bias, const float* res, int64_t res_bs,
                                            float* y, int64_t y_bs, int B, int Ci, int Co, int H, int W,
                                            float out_scale, int tile_cfg, float* gn_ostats_out,
-                                           const float* wmeta, lc_conv_range* range, lc_stream_t s) {
-    if (!x_split || !wp_hi || !wp_lo || !y || !wmeta || !range || B <= 0 || Ci <= 0 || Co <= 0 ||
-        H <= 0 || W <= 0)
+                                           float* splitk_part, int ksplit, const float* wmeta,
+                                           lc_conv_range* range, lc_stream_t s) {
+    if (!x_split || !wp_hi || !wp_lo || (!y && !splitk_part) || !wmeta || !range || B <= 0 || Ci <= 0 ||
+        Co <= 0 || H <= 0 || W <= 0)
         return LC_EINVAL;
     if (Ci % 16) return LC_EUNSUP;
+    if (splitk_part && (ksplit < 2 || ksplit > Ci / 16)) return LC_EINVAL;
     if ((long long)H * W >= (1 << 24) || (long long)2 * (Ci / 8) * H * W * 16 >= (1ll << 31)) return LC_EUNSUP;
     ConvArgsH a;
     a.x = nullptr; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
@@ -1446,6 +1481,7 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
     // the kernel addresses the lo plane as hi + one plane: the two must be one allocation
     if (a.wl != a.wh + (long long)9 * a.Cib * a.Cop) return LC_EINVAL;
     a.xsp = (const half8*)x_split; a.xsp_c8 = Ci / 8; a.xsp_bs = (long long)2 * (Ci / 8) * H * W;
+    a.part = splitk_part; a.ksplit = splitk_part ? ksplit : 0;
     a.out_scale = out_scale;
     a.tiles_h = a.tiles_w = 0;
     a.gn = nullptr; a.Cgn = 0; a.gn_silu = 0;
@@ -1457,10 +1493,76 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci < 24 ? 24 : Ci, Co, H, W, 3);
     if (pipe_stat_slots(tile_cfg, H, W) <= 0) return LC_EUNSUP;
     a.ostats = nullptr; a.oslots = 0;
-    if (gn_ostats_out) {
+    if (gn_ostats_out && !splitk_part) {
         a.oslots = pipe_stat_slots(tile_cfg, H, W);
         if (Co % 8) return LC_EUNSUP;
         a.ostats = reinterpret_cast<f32x4*>(gn_ostats_out);
     }
     return dispatch_h<3>(tile_cfg, a, lc_s(s));
+}
+
+// ---- split-K finish ------------------------------------------------------------------------------
+namespace {
+// y = (sum_z part[z] + bias [+ res]) * out_scale, one thread per (pixel, channel octet): the ksplit
+// partial planes are summed in index order (deterministic), optional GroupNorm statistics of what
+// is stored in the entry format of the conv epilogue (one entry per octet and wave of 64 pixels).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ks,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ res,
+                                                           long long res_bs, float* __restrict__ y,
+                                                           long long y_bs, int B, int Co, int HW,
+                                                           float out_scale, f32x4* __restrict__ ostats,
+                                                           int oslots) {
+    const int b = blockIdx.z, oct = blockIdx.y, c0 = oct * 8;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool pok = p < HW;
+    const long long plane = (long long)B * Co * HW;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float acc = 0.0f;
+        if (pok && c0 + k < Co) {
+            const float* pp = part + ((long long)b * Co + c0 + k) * HW + p;
+            for (int z = 0; z < ks; ++z) acc += pp[z * plane];
+            if (bias) acc += bias[c0 + k];
+            if (res) acc += res[b * res_bs + (long long)(c0 + k) * HW + p];
+            acc *= out_scale;
+            y[b * y_bs + (long long)(c0 + k) * HW + p] = acc;
+        }
+        v[k] = acc;
+    }
+    if (ostats) {                                  // Co % 8 == 0 (checked by the launcher)
+        const float piv = __builtin_amdgcn_readfirstlane(v[0]);
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = pok ? v[k] - piv : 0.0f;
+            s_ += d; q_ = fmaf(d, d, q_);
+        }
+        const int nvalid = __popcll(__ballot(pok));
+        s_ = wave_sum_to_lane63(s_);
+        q_ = wave_sum_to_lane63(q_);
+        const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 63 && slot < oslots)
+            ostats[((long long)b * (Co >> 3) + oct) * oslots + slot] =
+                f32x4{piv, (float)(8 * nvalid), s_, q_};
+    }
+}
+}  // namespace
+
+extern "C" int64_t lc_splitk_stats_slots(int H, int W) {
+    return H > 0 && W > 0 ? ((int64_t)H * W + 255) / 256 * 4 : 0;
+}
+
+extern "C" int lc_splitk_reduce(const float* part, int ksplit, const float* bias, const float* res,
+                                int64_t res_bs, float* y, int64_t y_bs, int B, int Co, int H, int W,
+                                float out_scale, float* gn_ostats_out, lc_stream_t s) {
+    if (!part || !y || ksplit < 1 || B <= 0 || Co <= 0 || H <= 0 || W <= 0) return LC_EINVAL;
+    if (gn_ostats_out && Co % 8) return LC_EUNSUP;
+    const int HW = H * W;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((HW + 255) / 256, (Co + 7) / 8, B), dim3(256), 0,
+                       lc_s(s), part, ksplit, bias, res, (long long)res_bs, y, (long long)y_bs, B, Co, HW,
+                       out_scale, reinterpret_cast<f32x4*>(gn_ostats_out),
+                       (int)lc_splitk_stats_slots(H, W));
+    return lc_launch_status();
 }

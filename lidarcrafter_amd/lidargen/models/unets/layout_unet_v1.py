@@ -81,14 +81,18 @@ class ResBlock(TimestepBlock):
             a = None
             h = self.in_layers[2](x, gn_coeffs=gn32_coeffs(self.in_layers[0], x), emit_stats=True)
         else:
-            a = self.in_layers[0](x, act_silu=True)
+            a = self.in_layers[0](x, act_silu=True, split_for=self.in_layers[2]._packed)
             h = self.in_layers[2](a, emit_stats=True)   # statistics for out_layers[0]
+            if isinstance(a, K.SplitAct):
+                a = None
         if fuse:
             sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
             return self.out_layers[3](h, res=sk, out=out, emit_stats=True,
                                       gn_coeffs=gn32_coeffs(self.out_layers[0], h, scale, shift))
-        a2 = self.out_layers[0](h, scale, shift, act_silu=True,
-                                out=a if a is not None and a.shape == h.shape else None)
+        reuse = a if a is not None and a.shape == h.shape and not K.can_presplit(
+            self.out_channels, self.out_layers[0].num_groups) else None
+        a2 = self.out_layers[0](h, scale, shift, act_silu=True, out=reuse,
+                                split_for=self.out_layers[3]._packed)
         sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
         return self.out_layers[3](a2, res=sk, out=out, emit_stats=True)   # ... for the next block's norm
 

@@ -20,7 +20,12 @@ class SiLU(nn.Module):
 class GroupNorm32(nn.GroupNorm):
     """fp32 GroupNorm on [B,C,H,W] or [B,C,L] (+ optional scale/shift, + optional SiLU)."""
 
-    def forward(self, x, scale=None, shift=None, act_silu: bool = False, out=None):
+    def forward(self, x, scale=None, shift=None, act_silu: bool = False, out=None, split_for=None):
+        """split_for: the `_packed` of the 3x3 conv consuming the result (pre-split output where the
+        shape allows: whole channel octets per group, i.e. C >= 256 with 32 groups)."""
+        if x.dim() == 4 and split_for is not None and out is None:
+            return K.groupnorm(x, self.num_groups, self.eps, self.weight, self.bias, scale, shift,
+                               act_silu=act_silu, split_for=split_for)
         if x.dim() == 3:
             B, C, L = x.shape
             o4 = None if out is None else out.view(B, C, 1, L)

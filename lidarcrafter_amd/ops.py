@@ -673,21 +673,63 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
     if bias is not None:
         _req(bias, "bias")
     _drop_stats(out)
+    ks = splitk_factor(B, Ci, Co, H, W) if tile_cfg == 0 else 0
     with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9):
         sbuf, slots = None, 0
-        if emit_stats and PRODUCER_GN_STATS:
-            slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, max(Ci, 24), Co, H, W, 3,
-                                                               int(tile_cfg)))
-            if slots > 0:
+        want_stats = emit_stats and PRODUCER_GN_STATS and Co % 8 == 0
+        if ks >= 2:
+            # small grid: ksplit blocks per tile over disjoint K ranges + one deterministic reduce
+            part = torch.empty((ks, B, Co, H, W), device=dev, dtype=_F32)
+            check(lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+                                                    None, None, 0, None, 0, B, Ci, Co, H, W, 1.0, 0,
+                                                    None, part.data_ptr(), ks,
+                                                    packed.wmeta.data_ptr(), packed.range_ptr(dev),
+                                                    _stream()), "lc_conv2d_ring_f16x2_ps_fwd")
+            if want_stats:
+                slots = int(lib().lc_splitk_stats_slots(H, W))
                 sbuf = torch.empty((B, Co // 8, slots, 4), device=dev, dtype=_F32)
-        check(lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
-                                                _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B, Ci,
-                                                Co, H, W, float(out_scale), int(tile_cfg), _p(sbuf),
-                                                packed.wmeta.data_ptr(), packed.range_ptr(dev),
-                                                _stream()), "lc_conv2d_ring_f16x2_ps_fwd")
+            check(lib().lc_splitk_reduce(part.data_ptr(), ks, _p(bias), _p(res), r_bs, out.data_ptr(),
+                                         y_bs, B, Co, H, W, float(out_scale), _p(sbuf), _stream()),
+                  "lc_splitk_reduce")
+        else:
+            if want_stats:
+                slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, max(Ci, 24), Co, H, W, 3,
+                                                                   int(tile_cfg)))
+                if slots > 0:
+                    sbuf = torch.empty((B, Co // 8, slots, 4), device=dev, dtype=_F32)
+            check(lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+                                                    _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
+                                                    Ci, Co, H, W, float(out_scale), int(tile_cfg),
+                                                    _p(sbuf), None, 0, packed.wmeta.data_ptr(),
+                                                    packed.range_ptr(dev), _stream()),
+                  "lc_conv2d_ring_f16x2_ps_fwd")
         if sbuf is not None:
             _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H, W)))
     return out
+
+
+# Split-K (pre-split conv): when a 3x3 conv has fewer than SPLITK_MAX_BLOCKS output tiles (batch
+# 1-2 at the deep levels), its K range is divided over several blocks per tile.
+SPLITK = _os.environ.get("LC_SPLITK", "1") != "0"
+SPLITK_MAX_BLOCKS = int(_os.environ.get("LC_SPLITK_MAX_BLOCKS", "64"))
+
+
+def splitk_factor(B: int, Ci: int, Co: int, H: int, W: int) -> int:
+    """Blocks per output tile for the pre-split conv (0 / 1 = no split)."""
+    if not SPLITK or Ci % 16:
+        return 0
+    nchunk = Ci // 16
+    # the tile shapes the heuristic would pick: 64 co x 256 / 128 / 64 px
+    px = B * H * W
+    co_blocks = (Co + 63) // 64
+    for tile in (256, 128, 64):
+        blocks = co_blocks * ((px + tile - 1) // tile)
+        if blocks >= 256 or tile == 64:
+            break
+    if blocks > SPLITK_MAX_BLOCKS or nchunk < 4:
+        return 0
+    ks = min(8, nchunk // 2, max(1, 256 // blocks))
+    return ks if ks >= 2 else 0
 
 
 # ------------------------------------------------------------------------------------ norm

@@ -126,3 +126,39 @@ def test_presplit_range_contract_moves_to_the_producer(dev):
         assert bad[0].layer == "ps_range"
         n_bad += 1
     assert n_bad == 1 and rel_l2(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(1, 512, 512, 4, 128), (1, 256, 256, 4, 128), (2, 256, 96, 4, 64),
+                                         (1, 64, 64, 5, 50), (1, 512, 256, 4, 128)])
+def test_conv_presplit_split_k(dev, B, Ci, Co, H, W):
+    """Small grids: the K range of a tile is divided over several blocks (lc_conv2d_ring_f16x2_ps_fwd
+    with splitk_part) and finished by lc_splitk_reduce -- same result as the single-block path to
+    fp32-class accuracy, deterministic, and the reduce pass's GroupNorm statistics drive the next
+    GroupNorm to the two-pass result."""
+    from lidarcrafter_amd import ops as K
+    from oracle import denoiser as D
+
+    ks = K.splitk_factor(B, Ci, Co, H, W)
+    assert ks >= 2, "shape chosen to take the split-K route"
+    x = seeded_randn(B, Ci, H, W, seed=41)
+    w = seeded_randn(Co, Ci, 3, 3, seed=42) / (Ci * 9) ** 0.5
+    b = seeded_randn(Co, seed=43)
+    res = seeded_randn(B, Co, H, W, seed=44)
+    a_ref = D.silu(D.group_norm(x, 8, None, None, 1e-6))
+    ref = (D.conv_ring(a_ref, w, b) + res) * 0.7071
+    pk = K.PackedConv("splitk")
+    sa = K.groupnorm(x.to(dev), 8, 1e-6, act_silu=True, split_for=pk)
+    y = K.conv2d_ring(sa, pk, w.to(dev), b.to(dev), res=res.to(dev), out_scale=0.7071, emit_stats=True)
+    assert rel_l2(y, ref) < 2e-6, rel_l2(y, ref)
+    y2 = K.conv2d_ring(sa, pk, w.to(dev), b.to(dev), res=res.to(dev), out_scale=0.7071)
+    assert torch.equal(y, y2)                                     # deterministic, stats do not change y
+    old = K.SPLITK
+    K.SPLITK = False
+    try:
+        y1 = K.conv2d_ring(sa, pk, w.to(dev), b.to(dev), res=res.to(dev), out_scale=0.7071)
+    finally:
+        K.SPLITK = old
+    assert rel_l2(y, y1) < 1e-6
+    if Co % 64 == 0:
+        assert K._find_stats(y, 8) is not None
+        assert rel_l2(K.groupnorm(y, 8, 1e-6), K.groupnorm(y.clone(), 8, 1e-6)) < 2e-6
