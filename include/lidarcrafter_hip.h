@@ -290,6 +290,36 @@ int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_t b_bs, flo
                  int64_t y_bs, int B, int64_t n, float scale, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
+ * BACKWARD kernels (training: tools/train/train_lidm[_cond].py:259-322 run autograd through the
+ * denoiser).  Plain fp32 NCHW tensors with batch strides as in the forward.
+ *
+ * Ring convolution.  The gradient with respect to the input is the SAME ring convolution applied to
+ * dY with the transposed, 180-degree rotated kernel (run lc_conv2d_ring_*_fwd on it); the gradient
+ * with respect to the weights and bias is lc_conv2d_ring_wgrad:
+ *   dW[co][ci][ky][kx] (+)= sum_{b,h,w} dY[b,co,h,w] * Xpad[b,ci,h+ky-1,w+kx-1],  db[co] (+)= sum dY
+ * fp32 matrix cores (exact fp32 products, fp32 accumulation), deterministic two-stage reduction;
+ * scratch: lc_conv2d_ring_wgrad_scratch_elems floats; dbias may be NULL; accumulate != 0 adds to
+ * dw / dbias (gradient accumulation), 0 overwrites.
+ *
+ * GroupNorm (+affine) (+AdaGN scale/shift) (+SiLU), forward y = silu?(((x-mu) rstd g + be)(1+sc) + sf):
+ *   lc_groupnorm_meanrstd: (mean, rstd) per (sample, group) [B, G, 2] from the lc_groupnorm_stats partials;
+ *   lc_groupnorm_bwd: rows[b][c] = (sum_hw dt2, sum_hw dt2 * xhat) as doubles [B, C, 2] with
+ *   dt2 = dy * silu'(.), and dx = rstd (g (1+sc) dt2 - mean_g(.) - xhat mean_g(. xhat)).  The small
+ *   parameter gradients follow from `rows`: dshift = r1, dscale = g r3 + be r1,
+ *   dbeta = sum_b (1+sc) r1, dgamma = sum_b (1+sc) r3.
+ * ------------------------------------------------------------------------------------------- */
+int64_t lc_conv2d_ring_wgrad_scratch_elems(int B, int Ci, int Co, int H, int W, int ks);
+int lc_conv2d_ring_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* scratch,
+                         float* dw /* [Co,Ci,ks,ks] */, float* dbias /* [Co] or NULL */, int B, int Ci,
+                         int Co, int H, int W, int ks, int accumulate, lc_stream_t s);
+int lc_groupnorm_meanrstd(const float* x, int64_t x_bs, const double* partials, float* mean_rstd,
+                          int B, int C, int H, int W, int G, float eps, lc_stream_t s);
+int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                     const float* mean_rstd, const float* gamma, const float* beta, const float* scale,
+                     const float* shift, int64_t ss_bs, double* rows, float* dx, int64_t dx_bs, int B,
+                     int C, int H, int W, int G, int act_silu, lc_stream_t s);
+
+/* ---------------------------------------------------------------------------------------------
  * Voxel scatter of the weight-free metrics (lidargen/metrics/metric_utils.py).
  * lc_bev_occupancy_accumulate: ONE sweep of pcd2bev_sum (:233-258): points with x in (x0, x1) and
  *   y in (y0, y1) are binned to ix = floor(x / voxel) - min_bound_x (float32 division, as numpy),

@@ -1,0 +1,249 @@
+"""Training path of the denoiser: autograd through the HIP kernels.
+
+The reference trains by running PyTorch autograd through the nn.Modules of the denoiser
+(tools/train/train_lidm.py:214-265, train_lidm_cond.py:259-322: `loss = ddpm(x_0)`,
+`accelerator.backward(loss)`, AdamW, EMA).  The inference forward of this build is not an autograd
+graph (fused GroupNorm, statistics hand-overs, pre-split activations, in-place concat buffers), so
+training takes a second, plain composition of the same layers in which every heavy op is a
+`torch.autograd.Function` over the C ABI:
+
+  ConvRing      forward  lc_conv2d_ring_*_fwd
+                backward dX: the same ring convolution of dY with the transposed, 180-degree rotated
+                         kernel (forward kernel);  dW, db: lc_conv2d_ring_wgrad (fp32 MFMA implicit
+                         GEMM over pixels, deterministic two-stage reduction)
+  GroupNormAct  forward  lc_groupnorm_stats + lc_groupnorm_apply (+ AdaGN scale/shift, + SiLU)
+                backward lc_groupnorm_bwd (rows + dx); parameter gradients contracted from the rows
+  Resample2x    forward  lc_resample2x_fwd;  backward: the adjoint FIR = the opposite resampling
+                         (down^T = up / 4, up^T = 4 down: same window, ring / zero padding)
+
+The per-step glue that is tiny next to those -- time MLP and AdaGN projections ([B, 256] dense layers),
+the attention core of the two 512-token MHA blocks (1.8 % of the FLOPs), residual adds, channel
+concatenation -- runs as differentiable torch ops ON THE DEVICE in this round (their HIP backward
+kernels are the next step); nothing runs on the CPU.  Gradient parity against autograd of the CPU
+oracle: tests/test_training.py.  Data-parallel training: the parameters are ordinary
+nn.Parameters, so torch DistributedDataParallel (RCCL bucketed all-reduce overlapped with backward)
+wraps `ddpm` unchanged, exactly like `accelerator.prepare` does in the reference.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import ops as K
+from ._lib import check, lib
+
+# arithmetic of the convolutions inside the training graph: "f32" = exact-fp32 MFMA kernels
+# (gradients of any magnitude are safe), "f16x2" = the split kernels (range-checked like inference)
+TRAIN_CONV_PRECISION = os.environ.get("LC_TRAIN_CONV_PRECISION", "f32")
+
+
+def training_active(module: torch.nn.Module, *tensors) -> bool:
+    """True when the caller expects an autograd graph: grad mode on and something requires grad."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+def _c4(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class ConvRing(torch.autograd.Function):
+    """y = conv_ring(x, W) + b (3x3: W circular / H zero padding, 1x1: plain)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, holder):
+        x = _c4(x)
+        y = K.conv2d_ring(x, holder["fwd"], weight, bias, precision=TRAIN_CONV_PRECISION)
+        ctx.save_for_backward(x, weight)
+        ctx.holder, ctx.has_bias = holder, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c4(dy)
+        B, Ci, H, W = x.shape
+        Co, ks = weight.shape[0], weight.shape[-1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [Ci, Co, ks, ks]
+            dx = K.conv2d_ring(dy, ctx.holder["bwd"], wt, None, precision=TRAIN_CONV_PRECISION)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight)
+            db = torch.empty(Co, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            n = int(lib().lc_conv2d_ring_wgrad_scratch_elems(B, Ci, Co, H, W, ks))
+            scratch = torch.empty(n, device=x.device, dtype=torch.float32)
+            with torch.cuda.device(x.device):
+                check(lib().lc_conv2d_ring_wgrad(x.data_ptr(), Ci * H * W, dy.data_ptr(), Co * H * W,
+                                                 scratch.data_ptr(), dw.data_ptr(),
+                                                 None if db is None else db.data_ptr(), B, Ci, Co, H,
+                                                 W, ks, 0, torch.cuda.current_stream().cuda_stream),
+                      "lc_conv2d_ring_wgrad")
+        return dx, dw, db, None
+
+
+def conv(module, x):
+    """Differentiable call of an ops.Conv2d / PointwiseConv1d-like module (weight [Co,Ci,k,k])."""
+    holder = module.__dict__.get("_train_packed")
+    if holder is None:
+        holder = {"fwd": K.PackedConv("train.fwd"), "bwd": K.PackedConv("train.bwd")}
+        module.__dict__["_train_packed"] = holder
+    w = module.weight if module.weight.dim() == 4 else module.weight[:, :, :, None]
+    return ConvRing.apply(x, w, module.bias, holder)
+
+
+class GroupNormAct(torch.autograd.Function):
+    """y = silu?( GN(x) * gamma + beta ) * (1 + scale) + shift ) -- any of gamma/beta, scale/shift None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, G, eps, act):
+        x = _c4(x)
+        B, C, H, W = x.shape
+        dev = x.device
+        sc = None if scale is None else scale.contiguous()
+        sf = None if shift is None else shift.contiguous()
+        n = int(lib().lc_groupnorm_partials_elems(B, C, H, W, G))
+        part = torch.empty(n, device=dev, dtype=torch.float64)
+        mr = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
+        y = torch.empty_like(x)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            check(lib().lc_groupnorm_stats(x.data_ptr(), C * H * W, part.data_ptr(), B, C, H, W, G, st),
+                  "lc_groupnorm_stats")
+            check(lib().lc_groupnorm_meanrstd(x.data_ptr(), C * H * W, part.data_ptr(), mr.data_ptr(), B,
+                                              C, H, W, G, float(eps), st), "lc_groupnorm_meanrstd")
+            check(lib().lc_groupnorm_apply(x.data_ptr(), C * H * W, part.data_ptr(), p(gamma), p(beta),
+                                           p(sc), p(sf), C, y.data_ptr(), C * H * W, B, C, H, W, G,
+                                           float(eps), int(act), st), "lc_groupnorm_apply")
+        ctx.save_for_backward(x, mr, gamma, beta, sc, sf)
+        ctx.G, ctx.act = G, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mr, gamma, beta, sc, sf = ctx.saved_tensors
+        dy = _c4(dy)
+        B, C, H, W = x.shape
+        rows = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
+        dx = torch.empty_like(x)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(x.device):
+            check(lib().lc_groupnorm_bwd(x.data_ptr(), C * H * W, dy.data_ptr(), C * H * W, mr.data_ptr(),
+                                         p(gamma), p(beta), p(sc), p(sf), C, rows.data_ptr(),
+                                         dx.data_ptr(), C * H * W, B, C, H, W, ctx.G, int(ctx.act),
+                                         torch.cuda.current_stream().cuda_stream), "lc_groupnorm_bwd")
+        r1, r3 = rows[..., 0], rows[..., 1]                       # [B, C] fp64
+        one_sc = 1.0 if sc is None else (1.0 + sc.double())
+        g = 1.0 if gamma is None else gamma.double()[None]
+        be = 0.0 if beta is None else beta.double()[None]
+        dgamma = dbeta = dscale = dshift = None
+        if gamma is not None:
+            dgamma = (one_sc * r3).sum(0).float()
+            dbeta = (one_sc * r1).sum(0).float()
+        if sc is not None:
+            dscale = (g * r3 + be * r1).float()
+            dshift = r1.float()
+        return dx, dgamma, dbeta, dscale, dshift, None, None, None
+
+
+def group_norm(module, x, act=False, scale=None, shift=None):
+    gamma = getattr(module, "weight", None)
+    beta = getattr(module, "bias", None)
+    return GroupNormAct.apply(x, gamma, beta, scale, shift, module.num_groups, module.eps, act)
+
+
+class Resample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, up):
+        ctx.up = up
+        return K.resample2x(_c4(x), up=up)
+
+    @staticmethod
+    def backward(ctx, dy):
+        # adjoint of the separable [1,3,3,1] FIR: the opposite direction with the same window;
+        # up carries a gain of 2 per axis, so down^T = up / 4 and up^T = 4 * down
+        g = K.resample2x(_c4(dy), up=not ctx.up)
+        return (g * 4.0 if ctx.up else g * 0.25), None
+
+
+def resample(x, up: bool):
+    return Resample2x.apply(x, up)
+
+
+# ------------------------------------------------------------------------------------------------
+def efficient_unet_forward(m, images: torch.Tensor, log_snr: torch.Tensor) -> torch.Tensor:
+    """Differentiable forward of lidargen.models.unets.EfficientUNet (reference
+    efficient_unet.py:274-300) on the Functions above; same parameters, same arithmetic order as the
+    reference modules (GN -> SiLU -> conv -> AdaGN -> SiLU -> conv, (skip + h) / sqrt(2), ...)."""
+    B = images.shape[0]
+    if log_snr.dim() == 0:
+        log_snr = log_snr[None].repeat_interleave(B, dim=0)
+    te = m.time_embedding
+    h = te[0](log_snr.float())                                   # sinusoid of the log-SNR (no parameters)
+    temb = F.linear(F.silu(F.linear(h, te[1].weight, te[1].bias)), te[3].weight, te[3].bias)
+    x = images
+    if m.coords_encoding is not None:
+        with torch.no_grad():
+            enc = m.coords_encoding(m.coords) if not isinstance(m.coords_encoding, torch.nn.Identity) \
+                else m.coords.float()
+        x = torch.cat([images, enc.expand(B, -1, -1, -1)], dim=1)
+
+    def res_block(rb, x):
+        h = conv(rb.conv1, group_norm(rb.norm1, x, act=True))
+        if rb.has_emb:
+            ss = F.linear(F.silu(temb), rb.norm2.proj[1].weight, rb.norm2.proj[1].bias)
+            C = rb.norm2.num_channels
+            h = group_norm(rb.norm2, h, act=True, scale=ss[:, :C], shift=ss[:, C:])
+        else:
+            h = group_norm(rb.norm2, h, act=True)
+        h = conv(rb.conv2, h)
+        sk = x if isinstance(rb.skip, torch.nn.Identity) else conv(rb.skip, x)
+        return (sk + h) * rb._scale_f
+
+    def attn_block(sa, x):
+        B_, C, H, W = x.shape
+        heads = sa.attn.num_heads
+        q = conv(_LinearAsConv(sa.attn.in_proj_weight, sa.attn.in_proj_bias, sa, "in"),
+                 group_norm(sa.norm, x))
+        q = q.view(B_, 3, heads, C // heads, H * W)
+        s = torch.einsum("bhct,bhcs->bhts", q[:, 0], q[:, 1]) * (C // heads) ** -0.5
+        o = torch.einsum("bhts,bhcs->bhct", s.softmax(-1), q[:, 2]).reshape(B_, C, H, W)
+        o = conv(_LinearAsConv(sa.attn.out_proj.weight, sa.attn.out_proj.bias, sa, "out"), o)
+        return (x + o) * sa._scale_f
+
+    def block(blk, h):
+        if not isinstance(blk.downsample, torch.nn.Identity):
+            h = resample(conv(blk.downsample[0], h), up=False)
+        for rb in blk.residual_blocks:
+            h = res_block(rb, h)
+        if not isinstance(blk.self_attn_block, torch.nn.Identity):
+            h = attn_block(blk.self_attn_block, h)
+        if not isinstance(blk.upsample, torch.nn.Identity):
+            h = conv(blk.upsample[1], resample(h, up=True))
+        return h
+
+    h = conv(m.in_conv, x)
+    h1 = block(m.d_block1, h)
+    h2 = block(m.d_block2, h1)
+    h3 = block(m.d_block3, h2)
+    h4 = block(m.d_block4, h3)
+    h = block(m.u_block4, h4)
+    h = block(m.u_block3, torch.cat([h, h3], dim=1))
+    h = block(m.u_block2, torch.cat([h, h2], dim=1))
+    h = block(m.u_block1, torch.cat([h, h1], dim=1))
+    return conv(m.out_conv, h)
+
+
+class _LinearAsConv:
+    """A [N, K] dense weight seen as a 1x1 conv of channel-major tokens (the MHA projections)."""
+
+    def __init__(self, weight, bias, owner, tag):
+        self.weight, self.bias = weight[:, :, None, None], bias
+        self.__dict__["_train_packed"] = owner.__dict__.setdefault(
+            "_train_packed_" + tag, {"fwd": K.PackedConv("train.fwd"), "bwd": K.PackedConv("train.bwd")})

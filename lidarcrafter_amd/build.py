@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblidarcrafter_hip.so")
-SOURCES = ["conv.hip", "conv_f16x2.hip", "norm.hip", "resample.hip", "misc.hip", "attention.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip"]
+SOURCES = ["conv.hip", "conv_f16x2.hip", "norm.hip", "resample.hip", "misc.hip", "attention.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip", "conv_bwd.hip"]
 
 
 def hipcc() -> str:

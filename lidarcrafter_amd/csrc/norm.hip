@@ -234,6 +234,103 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
+// ---------------------------------------------------------------------------------------------
+// BACKWARD of GroupNorm (+affine) (+AdaGN scale/shift) (+SiLU)  -- training, SURVEY.md section 8f-4.
+//   forward:  xh = (x - mu) rstd;  t1 = xh g + be;  t2 = t1 (1 + sc) + sf;  y = silu?(t2)
+//   backward: dt2 = dy silu'(t2);  r1[b,c] = sum_hw dt2,  r3[b,c] = sum_hw dt2 xh      (rows kernel)
+//             dxh = g (1 + sc) dt2;   dx = rstd (dxh - mean_g(dxh) - xh mean_g(dxh xh))   (apply kernel)
+//   the parameter gradients are small contractions of the rows (host side of the C ABI's caller):
+//     dsf = r1, dsc = g r3 + be r1, dbe = sum_b (1+sc) r1, dg = sum_b (1+sc) r3.
+__global__ void gn_meanrstd_kernel(const double* __restrict__ part, const float* __restrict__ x,
+                                   long long x_bs, float* __restrict__ out, int B, int C, int G,
+                                   long long HW, int nch, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G, cpg = C / G;
+    const double* pp = part + (long long)i * nch * 2;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nch; ++k) { s += pp[2 * k]; q += pp[2 * k + 1]; }
+    const double n = (double)cpg * (double)HW;
+    const double dm = s / n;
+    double var = q / n - dm * dm;
+    if (var < 0.0) var = 0.0;
+    out[2 * i] = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
+    out[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__device__ __forceinline__ float silu_grad(float t) {
+    const float sg = 1.0f / (1.0f + __expf(-t));
+    return sg * (1.0f + t * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_rows_kernel(
+    const float* __restrict__ x, long long x_bs, const float* __restrict__ dy, long long dy_bs,
+    const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ scale, const float* __restrict__ shift, long long ss_bs,
+    double* __restrict__ rows, int C, int G, long long HW, int act) {
+    const int c = blockIdx.x, b = blockIdx.y, g = c / (C / G);
+    const float mu = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+    const float sf = shift ? shift[b * ss_bs + c] : 0.0f;
+    const float* xp = x + b * x_bs + (long long)c * HW;
+    const float* dp = dy + b * dy_bs + (long long)c * HW;
+    double r1 = 0.0, r3 = 0.0;
+    for (long long i0 = threadIdx.x; i0 < HW; i0 += 256 * 16) {
+        float a1 = 0.f, a3 = 0.f;                              // fp32 over <= 16 values, then fp64
+        for (long long i = i0; i < HW && i < i0 + 256 * 16; i += 256) {
+            const float xh = (xp[i] - mu) * rstd;
+            float d = dp[i];
+            if (act) d *= silu_grad((xh * ga + be) * sc + sf);
+            a1 += d; a3 += d * xh;
+        }
+        r1 += (double)a1; r3 += (double)a3;
+    }
+    r1 = lc_wave_sum(r1); r3 = lc_wave_sum(r3);
+    __shared__ double sh[8];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[w] = r1; sh[4 + w] = r3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rows[2 * ((long long)b * C + c)] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        rows[2 * ((long long)b * C + c) + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
+    const float* __restrict__ x, long long x_bs, const float* __restrict__ dy, long long dy_bs,
+    const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ scale, const float* __restrict__ shift, long long ss_bs,
+    const double* __restrict__ rows, float* __restrict__ dx, long long dx_bs, int C, int G,
+    long long HW, int act) {
+    const int c = blockIdx.y, b = blockIdx.z, cpg = C / G, g = c / cpg;
+    const float mu = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+    double m1 = 0.0, m2 = 0.0;                                  // group means of dxh and dxh * xh
+    for (int k = 0; k < cpg; ++k) {
+        const int cc = g * cpg + k;
+        const double w = (double)(gamma ? gamma[cc] : 1.0f) *
+                         (double)(scale ? 1.0f + scale[b * ss_bs + cc] : 1.0f);
+        m1 += w * rows[2 * ((long long)b * C + cc)];
+        m2 += w * rows[2 * ((long long)b * C + cc) + 1];
+    }
+    const double n = (double)cpg * (double)HW;
+    const float fm1 = (float)(m1 / n), fm2 = (float)(m2 / n);
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+    const float sf = shift ? shift[b * ss_bs + c] : 0.0f;
+    const float* xp = x + b * x_bs + (long long)c * HW;
+    const float* dp = dy + b * dy_bs + (long long)c * HW;
+    float* op = dx + b * dx_bs + (long long)c * HW;
+    const long long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float xh = (xp[i] - mu) * rstd;
+        float d = dp[i];
+        if (act) d *= silu_grad((xh * ga + be) * sc + sf);
+        op[i] = rstd * (ga * sc * d - fm1 - xh * fm2);
+    }
+}
+
 template <bool OS>
 __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     const float* __restrict__ x, long long x_bs, const double* __restrict__ part, OctStats2 os,
@@ -480,5 +577,35 @@ extern "C" int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const l
                        lc_s(s), x, (long long)x_bs, nullptr, os, gamma, beta, scale, shift,
                        (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
                        (long long)2 * (C / 8) * HW, C, G, HW, 0, eps, act_silu, range);
+    return lc_launch_status();
+}
+
+// ---- backward (training) ----------------------------------------------------------------------------
+extern "C" int lc_groupnorm_meanrstd(const float* x, int64_t x_bs, const double* partials,
+                                     float* mean_rstd, int B, int C, int H, int W, int G, float eps,
+                                     lc_stream_t s) {
+    if (!x || !partials || !mean_rstd || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
+    const long long HW = (long long)H * W;
+    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
+    hipLaunchKernelGGL(gn_meanrstd_kernel, dim3((B * G + 63) / 64), dim3(64), 0, lc_s(s), partials, x,
+                       (long long)x_bs, mean_rstd, B, C, G, HW, nch, eps);
+    return lc_launch_status();
+}
+
+extern "C" int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                                const float* mean_rstd, const float* gamma, const float* beta,
+                                const float* scale, const float* shift, int64_t ss_bs, double* rows,
+                                float* dx, int64_t dx_bs, int B, int C, int H, int W, int G,
+                                int act_silu, lc_stream_t s) {
+    if (!x || !dy || !mean_rstd || !rows || !dx || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
+    const long long HW = (long long)H * W;
+    hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3(C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs, dy,
+                       (long long)dy_bs, mean_rstd, gamma, beta, scale, shift, (long long)ss_bs, rows, C,
+                       G, HW, act_silu);
+    int slabs = (int)((HW + 4095) / 4096);
+    if (slabs < 1) slabs = 1;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(slabs, C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
+                       dy, (long long)dy_bs, mean_rstd, gamma, beta, scale, shift, (long long)ss_bs, rows,
+                       dx, (long long)dx_bs, C, G, HW, act_silu);
     return lc_launch_status();
 }

@@ -2,6 +2,7 @@
 (constructor arguments, `device`, `randn`/`randn_like` RNG contract, `p_loss`, `forward`)."""
 from __future__ import annotations
 
+import contextlib
 from typing import List, Literal
 
 import torch
@@ -107,11 +108,16 @@ class GaussianDiffusion(nn.Module):
         return (loss * self.get_loss_weight(steps)).mean()
 
     def p_loss(self, x_0, steps, loss_mask=None):
-        """Loss VALUE of one denoising step (reference base.py:124-143).  The HIP denoiser has no
-        backward pass yet (training = SURVEY.md §8f-4), so this is evaluation-only."""
+        """Loss of one denoising step (reference base.py:124-143).  With grad mode on and trainable
+        parameters the denoiser builds an autograd graph over the HIP kernels
+        (lidarcrafter_amd/autograd.py: EfficientUNet this round), so `ddpm(x_0).backward()` works as in
+        tools/train/train_lidm.py:214-265; otherwise only the value is computed."""
         loss_mask = torch.ones_like(x_0) if loss_mask is None else loss_mask
         x_t, noise = self.q_step_from_x_0(x_0, steps)
-        with torch.no_grad():
+        from lidarcrafter_amd import autograd as AG
+
+        train = AG.training_active(self.model) and hasattr(self.model, "d_block1")
+        with (contextlib.nullcontext() if train else torch.no_grad()):
             prediction = self.model(x_t, self.get_network_condition(steps))
         return self._masked_loss(prediction, self.get_target(x_0, steps, noise), loss_mask, steps)
 

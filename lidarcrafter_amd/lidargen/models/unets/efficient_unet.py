@@ -19,6 +19,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from lidarcrafter_amd import autograd as AG
 from lidarcrafter_amd import ops as K
 
 from . import encoding, ops
@@ -277,6 +278,9 @@ class EfficientUNet(nn.Module):
         `time_features`: optional precomputed `self.time_features(log_snr)` (sampler hoists it).
         Range-checked: a standalone call polls the conv range records afterwards and recomputes if
         a layer's fp16 operands saturated (ops.range_checked); samplers defer that to the run's end."""
+        if time_features is None and AG.training_active(self, images):
+            # training (tools/train/train_lidm.py): the differentiable composition of the same layers
+            return AG.efficient_unet_forward(self, images, timesteps.to(images))
         B, _, H, W = images.shape
         if time_features is None:
             if timesteps.dim() == 0:

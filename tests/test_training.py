@@ -1,0 +1,142 @@
+"""Training path: gradients of the HIP autograd Functions
+(lidarcrafter_amd/autograd.py) against torch autograd of the CPU oracle on identical seeded
+weights / inputs: per-op (ring conv dX / dW / db, GroupNorm + AdaGN + SiLU, FIR resampling) and the
+whole reduced EfficientUNet through the diffusion loss `ddpm(x_0)` as tools/train/train_lidm.py calls
+it, plus one optimizer step.  `pytest -m gpu`."""
+import pytest
+import torch
+
+from lidarcrafter_amd.testing import rel_l2, seeded_fill, seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(2, 5, 7, 4, 16, 3), (1, 64, 64, 8, 128, 3), (2, 96, 130, 5, 50, 3),
+                                            (2, 64, 32, 4, 200, 1), (1, 128, 256, 4, 128, 3)])
+def test_conv_gradients(dev, B, Ci, Co, H, W, ks):
+    from lidarcrafter_amd import autograd as AG
+    from oracle import denoiser as D
+
+    x = seeded_randn(B, Ci, H, W, seed=1)
+    w = seeded_randn(Co, Ci, ks, ks, seed=2) / (Ci * ks * ks) ** 0.5
+    b = seeded_randn(Co, seed=3)
+    g = seeded_randn(B, Co, H, W, seed=4)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    D.conv_ring(xr, wr, br).backward(g)
+
+    class M:
+        pass
+
+    m = M()
+    m.weight = w.to(dev).requires_grad_()
+    m.bias = b.to(dev).requires_grad_()
+    xd = x.to(dev).requires_grad_()
+    y = AG.conv(m, xd)
+    y.backward(g.to(dev))
+    assert rel_l2(y, D.conv_ring(x, w, b)) < 2e-6
+    assert rel_l2(xd.grad, xr.grad) < 2e-6, rel_l2(xd.grad, xr.grad)
+    assert rel_l2(m.weight.grad, wr.grad) < 2e-6, rel_l2(m.weight.grad, wr.grad)
+    assert rel_l2(m.bias.grad, br.grad) < 2e-6
+
+
+@pytest.mark.parametrize("B,C,H,W,G", [(2, 16, 4, 8, 8), (1, 64, 8, 128, 8), (3, 96, 5, 50, 32)])
+@pytest.mark.parametrize("mode", ["affine", "adagn", "plain"])
+@pytest.mark.parametrize("act", [True, False])
+def test_groupnorm_gradients(dev, B, C, H, W, G, mode, act):
+    from lidarcrafter_amd import autograd as AG
+    from oracle import denoiser as D
+
+    x = seeded_randn(B, C, H, W, seed=11) * 2 + 0.3
+    g = seeded_randn(B, C, H, W, seed=12)
+    leaves = {"x": x}
+    if mode == "affine":
+        leaves.update(gamma=1 + 0.2 * seeded_randn(C, seed=13), beta=0.3 * seeded_randn(C, seed=14))
+    if mode == "adagn":
+        leaves.update(scale=0.3 * seeded_randn(B, C, seed=15), shift=0.3 * seeded_randn(B, C, seed=16))
+
+    def run(t):
+        y = D.group_norm(t["x"], G, t.get("gamma"), t.get("beta"), 1e-6)
+        if "scale" in t:
+            y = y * (1 + t["scale"][:, :, None, None]) + t["shift"][:, :, None, None]
+        return D.silu(y) if act else y
+
+    ref = {k: v.clone().requires_grad_() for k, v in leaves.items()}
+    run(ref).backward(g)
+    d = {k: v.to(dev).requires_grad_() for k, v in leaves.items()}
+    y = AG.GroupNormAct.apply(d["x"], d.get("gamma"), d.get("beta"), d.get("scale"), d.get("shift"),
+                              G, 1e-6, act)
+    y.backward(g.to(dev))
+    assert rel_l2(y, run(leaves)) < 2e-6
+    for k in leaves:
+        r = rel_l2(d[k].grad, ref[k].grad)
+        assert r < 5e-6, (k, r)
+
+
+@pytest.mark.parametrize("up", [True, False])
+def test_resample_gradient_is_the_adjoint(dev, up):
+    from lidarcrafter_amd import autograd as AG
+    from oracle import denoiser as D
+
+    x = seeded_randn(2, 3, 8, 32, seed=21)
+    f = D.resample_up2 if up else D.resample_down2
+    xr = x.clone().requires_grad_()
+    y = f(xr)
+    g = seeded_randn(*y.shape, seed=22)
+    y.backward(g)
+    xd = x.to(dev).requires_grad_()
+    AG.resample(xd, up=up).backward(g.to(dev))
+    assert rel_l2(xd.grad, xr.grad) < 2e-6
+
+
+def test_unet_loss_gradients_and_one_step(dev):
+    """`loss = ddpm(x_0); loss.backward()` on the reduced EfficientUNet: every parameter gradient vs
+    autograd of the oracle forward under the same timesteps / noise; then one AdamW step changes the
+    loss the same way on both sides."""
+    from lidargen.models.diffusion import ContinuousTimeGaussianDiffusion
+    from oracle import denoiser as D
+    from tests.test_hip_parity import _uncond
+
+    m = _uncond(16, (8, 64), dev).train()
+    ddpm = ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).to(dev)
+    x0 = seeded_randn(2, 2, 8, 64, seed=31).clamp(-1, 1)
+    steps = torch.tensor([0.7, 0.2])
+    noise = seeded_randn(2, 2, 8, 64, seed=32)
+    lam = ddpm.log_snr(steps)
+    alpha, sigma = lam.sigmoid().sqrt(), (-lam).sigmoid().sqrt()
+    x_t = x0 * alpha + noise * sigma
+    # device side: the model inside the training graph
+    pred = m(x_t.to(dev), lam[:, 0, 0, 0].to(dev))
+    assert pred.requires_grad
+    loss = ((pred - noise.to(dev)) ** 2).mean()
+    loss.backward()
+    # oracle side
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "scale" != k.split(".")[-1])
+          for k, v in m.state_dict().items()}
+    # (the oracle forward is decorated with torch.no_grad for its inference use: call the undecorated function)
+    fwd = getattr(D.efficient_unet_forward, "__wrapped__", D.efficient_unet_forward)
+    ref = ((fwd(sd, x_t, lam[:, 0, 0, 0]) - noise) ** 2).mean()
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        r = rel_l2(p.grad, sd[k].grad)
+        worst = max(worst, r)
+        assert r < 2e-4, (k, r)
+    # ddpm(x_0) is what the training scripts call (random timesteps inside): it must be differentiable
+    m.zero_grad()
+    opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-3)
+    l0 = ddpm(x0.to(dev))
+    l0.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    opt.step()
+    with torch.no_grad():
+        l1 = ((m(x_t.to(dev), lam[:, 0, 0, 0].to(dev)) - noise.to(dev)) ** 2).mean()
+    assert torch.isfinite(l1)
+    print(f"worst parameter-gradient rel-L2 {worst:.2e}")
