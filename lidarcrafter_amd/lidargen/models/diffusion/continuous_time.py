@@ -261,7 +261,6 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
         st["i"] = i + 1
         return x
 
-    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_size: int, num_steps: int, progress: bool = True, rng=None,
                return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",

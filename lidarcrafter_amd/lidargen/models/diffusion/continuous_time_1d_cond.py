@@ -78,7 +78,6 @@ class CondContinuousLayoutGaussianDiffusion1D(CondContinuousTimeGaussianDiffusio
             return self._img(super().randn(shape[0], shape[2], shape[3], rng=rng, **kwargs))
         return super().randn(*shape, rng=rng, **kwargs)
 
-    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_dict: dict, batch_size: int, num_steps: int, progress: bool = True,
                rng=None, return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",

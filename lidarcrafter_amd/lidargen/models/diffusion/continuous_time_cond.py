@@ -55,7 +55,6 @@ class CondContinuousTimeGaussianDiffusion(continuous_time.ContinuousTimeGaussian
         return K.pstep(x_t, pred, noise, coef.to(x_t.device), self._objective_id(),
                        schedules.MODES[mode])
 
-    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_dict: dict, batch_size: int, num_steps: int, progress: bool = True,
                rng=None, return_all: bool = False, mode: Literal["ddpm", "ddim"] = "ddpm",

@@ -10,6 +10,8 @@ import torch
 import torch.nn.functional as F
 from tqdm.auto import tqdm
 
+from lidarcrafter_amd import ops as K
+
 from . import base, schedules
 
 
@@ -92,16 +94,18 @@ class DiscreteTimeGaussianDiffusion(base.GaussianDiffusion):
             return x_s
         raise ValueError(f"invalid mode {mode}")
 
-    @torch.compiler.disable
     @torch.inference_mode()
     def sample(self, batch_size, num_steps, progress=True, rng=None, return_all=False,
                mode: Literal["ddpm", "ddim"] = "ddpm"):
-        x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
-        out = [x] if return_all else None
-        for ts in tqdm(list(reversed(range(num_steps))), desc="sampling", leave=False,
-                       disable=not progress):
-            steps = torch.full((batch_size,), ts, device=self.device).long()
-            x = self.p_step(x, steps, rng=rng, mode=mode)
-            if return_all:
-                out.append(x)
-        return torch.stack(out) if return_all else x
+        def run():
+            x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
+            out = [x] if return_all else None
+            for ts in tqdm(list(reversed(range(num_steps))), desc="sampling", leave=False,
+                           disable=not progress):
+                steps = torch.full((batch_size,), ts, device=self.device).long()
+                x = self.p_step(x, steps, rng=rng, mode=mode)
+                if return_all:
+                    out.append(x)
+            return torch.stack(out) if return_all else x
+
+        return K.run_range_safe(run, rng, self.device, "DiscreteTimeGaussianDiffusion.sample")

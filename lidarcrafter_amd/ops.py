@@ -411,8 +411,12 @@ def rng_restore(rng, snap) -> None:
             g.set_state(st)
 
 
+@torch.compiler.disable
 def run_range_safe(run, rng, device, what: str = "sampling run"):
-    """`run()` under deferred range checks; poll afterwards; if a layer computed from saturated
+    """(Opaque to Dynamo: `torch.compile(ddpm.sample)`, as the reference's bulk harness wraps it,
+    traces the trivial method body and calls this eagerly -- the loop inside already replays one
+    captured HIP graph per step.)
+    `run()` under deferred range checks; poll afterwards; if a layer computed from saturated
     operands, its pre-scale has been moved: restore the generators and run again (bit-identical
     draws), so the caller never sees a clipped trajectory."""
     if CONV_PRECISION != "f16x2" or torch.device(device).type != "cuda":

@@ -137,3 +137,45 @@ def test_ddim_advances_generators_like_reference(dev, golden):
         one = torch.Generator().manual_seed(510)
         ddpm.sample(2, 3, progress=False, rng=one, mode=mode)
         assert torch.equal(torch.randn(4, generator=one), T(g[f"{mode}_next_one"])), mode
+
+
+def test_bulk_harness_compile_and_autocast(dev):
+    """tools/evaluation/sample_and_save_cond.py:64,145 wraps the sampler in torch.compile and runs it
+    under fp16 autocast.  Here: `torch.compile(ddpm.sample)` must simply call the (graph-replaying)
+    sampler, and half-precision tensors produced by autocast (the layout encoder's nn.Linear outputs)
+    are up-cast at the op boundary -- the result stays within fp16-rounding distance of the fp32 run."""
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    m, enc = build_cond_pair((8, 64), 8, 32)
+    ddpm = CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval().to(dev)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(2, 8, 64, seed=51).items()}
+
+    def run(fn, amp):
+        rng = [torch.Generator().manual_seed(90 + i) for i in range(2)]
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            return fn(batch_dict=batch, batch_size=2, num_steps=4, progress=False, rng=rng, mode="ddim")
+
+    ref = run(ddpm.sample, False)
+    compiled = torch.compile(ddpm.sample)
+    out = run(compiled, False)
+    assert torch.equal(out, ref)
+    amp = run(compiled, True)
+    assert amp.dtype == torch.float32 and torch.isfinite(amp).all()
+    assert rel_l2(amp, ref) < 2e-2, rel_l2(amp, ref)
+
+
+def test_second_device_if_present(dev):
+    """kernels must launch on the device / stream of their tensors, not on the current
+    device (setup_model(device='cuda:1') without torch.cuda.set_device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("single-GPU box")
+    from lidarcrafter_amd import ops as K
+
+    d1 = torch.device("cuda:1")
+    x = seeded_randn(1, 16, 4, 64, seed=1)
+    w = seeded_randn(16, 16, 3, 3, seed=2) / 12
+    y0 = K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev))
+    assert torch.cuda.current_device() == 0
+    y1 = K.conv2d_ring(x.to(d1), K.PackedConv(), w.to(d1))
+    assert y1.device == d1 and torch.equal(y0.cpu(), y1.cpu()) and torch.cuda.current_device() == 0

@@ -673,7 +673,7 @@ def test_hip_graph_equals_eager(dev):
 
 # ------------------------------------------------------------------------------------- roi pooling
 @pytest.mark.parametrize("method", ["max", "avg"])
-def test_roiaware_pool3d(dev, method):
+def test_roiaware_pool3d_vs_unpinned_restatement(dev, method):
     """Forward bit-exact vs the numpy restatement of the reference kernels (incl. a voxel that
     overflows max_pts_each_voxel), backward within fp32 atomics tolerance."""
     from lidarcrafter_amd.testing import synth_boxes
@@ -821,7 +821,7 @@ def _temporal_scene(seed, H=32, W=1024, n_pts=30000, K_=5):
     return first, pts, item
 
 
-def test_custom_dataset_item(dev):
+def test_custom_dataset_item_vs_unpinned_restatement(dev):
     """CustomDataset.__getitem__ + pre_process on the device vs the oracle restatement."""
     import lidargen  # noqa: F401
     from lidargen.dataset import __all__ as DS
@@ -845,7 +845,7 @@ def test_custom_dataset_item(dev):
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_temporal_frame_glue(dev, seed):
+def test_temporal_frame_glue_vs_unpinned_restatement(dev, seed):
     """get_temporal_boxes_3d -> get_next_frame_points -> delete_fg_points for two frames, device
     vs oracle: identical point selections and order, coordinates bit-equal (same float64 4x4s)."""
     import lidargen  # noqa: F401
@@ -1069,7 +1069,7 @@ def test_discrete_time_sampler_golden(dev, golden):
 
 
 @pytest.mark.parametrize("B,N,M", [(2, 1000, 777), (1, 1, 5), (1, 512, 1024), (3, 300, 513)])
-def test_chamfer3d_bit_exact(dev, B, N, M):
+def test_chamfer3d_vs_unpinned_restatement(dev, B, N, M):
     """lc_chamfer3d_fwd vs the float32 numpy restatement: distances and indices identical,
     duplicates resolved to the first minimum; compute_pairwise_cd(_batch) on top of it."""
     import lidargen  # noqa: F401
