@@ -192,6 +192,70 @@ def pib(dev, N, nbox):
             "GBps": round(algo / dt / 1e9, 1), "frac_of_hbm_peak": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def train_step(dev, B):
+    """One training step of the C2 denoiser through the HIP autograd Functions (forward + backward +
+    AdamW), tools/train/train_lidm.py:214-265 at batch B, fp32-MFMA convolutions."""
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model, _ = inference.load_model_duffusion_training(C["nuscenes-unet-uncond"]())
+    seeded_fill(model, salt=100)
+    ddpm = ddpm.train().to(dev)
+    opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)
+    x0 = torch.randn(B, 2, 32, 1024, device=dev).clamp(-1, 1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ddpm(x0)
+        loss.backward()
+        opt.step()
+
+    dt = timed(step, 5, warm=2)
+    flop = 3 * B * GFLOP["uncond32"] * 1e9                       # forward + dX + dW
+    return {"batch": B, "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2),
+            "algorithmic_tflops": round(flop / dt / 1e12, 1),
+            "note": "forward + backward + AdamW, exact-fp32 MFMA convolutions (LC_TRAIN_CONV_PRECISION=f32)"}
+
+
+def object_branch(dev, n_obj, steps):
+    """Foreground-object branch: `steps` DDPM steps of PointUNet over n_obj x [1024, 4] point sets."""
+    from lidarcrafter_amd.testing import seeded_fill, synth_object_batch, synth_text_features
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model = inference.load_model_object_duffusion_training(C["nuscenes-object"]())
+    seeded_fill(model, salt=300), seeded_fill(ddpm.condition_model, salt=301)
+    ddpm = ddpm.eval().to(dev)
+    ddpm.condition_model.set_text_features(synth_text_features(), dev)
+    batch = {k: v.to(dev) for k, v in synth_object_batch(n_obj, seed=95).items()}
+    ddpm.sample(batch, n_obj, 8, progress=False, mode="ddpm")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = ddpm.sample(batch, n_obj, steps, progress=False, mode="ddpm")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    return {"objects": n_obj, "steps": steps, "seconds": round(dt, 3), "us_per_step": round(dt / steps * 1e6, 1)}
+
+
+def voxel_scatter(dev, n_sweeps, N):
+    """pcd2bev_sum ('32': 1200 x 1200 voxels of 5 cm) over n_sweeps sweeps of N points, and
+    sparse_quantize of one 4 M-point cloud."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_points
+    from lidargen.metrics import metric_utils as M
+
+    sweeps = [torch.from_numpy(synth_points(N, seed=i)).to(dev) for i in range(n_sweeps)]
+    dt = timed(lambda: M.pcd2bev_sum("32", sweeps), 5, warm=1)
+    big = torch.from_numpy(synth_points(1 << 22, seed=99)[:, :3].copy()).to(dev)
+    dq = timed(lambda: K.sparse_quantize(big, 0.1, return_index=True, return_inverse=True), 5, warm=1)
+    return {"pcd2bev_sum": {"sweeps": n_sweeps, "points_per_sweep": N, "ms": round(dt * 1e3, 3),
+                            "Mpoints_per_s": round(n_sweeps * N / dt / 1e6, 1)},
+            "sparse_quantize": {"points": 1 << 22, "ms": round(dq * 1e3, 3),
+                                "Mpoints_per_s": round((1 << 22) / dq / 1e6, 1)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -205,6 +269,9 @@ def main():
         out["uncond_64x2048"] = [uncond(dev, 4, (64, 2048), 6, "uncond64")]
     out["temporal_sequence_32x1024"] = [sequence(dev, 2, 5, 16 if args.quick else 32)]
     out["pipeline_metrics_c5_shape"] = [pipeline_metrics(dev, 8, 1 if args.quick else 2, 8)]
+    out["train_step_c2"] = [train_step(dev, B) for B in ((2,) if args.quick else (2, 8))]
+    out["object_branch"] = [object_branch(dev, 10, 256)]
+    out["voxel_scatter"] = [voxel_scatter(dev, 16, 34720)]
     out["projection"] = [projection(dev, N) for N in (34720, 131072, 1 << 22)]
     out["points_in_boxes_mask"] = [pib(dev, N, nb) for N, nb in ((34720, 13), (1 << 22, 13))]
     print(json.dumps(out, indent=1))

@@ -407,11 +407,7 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     const long long per = (HW + gridDim.x - 1) / gridDim.x;
     const long long lo = blockIdx.x * per;
     const long long hi = lo + per < HW ? lo + per : HW;
-    for (long long p = lo + threadIdx.x; p < hi; p += 256) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = xp[(long long)k * HW + p];
-        half8_t h8, l8;
+    auto one = [&](const float (&v)[8], half8_t& h8, half8_t& l8) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
             float t0 = (v[k] - mu) * rstd, t1 = (v[k + 1] - mu) * rstd;
@@ -427,8 +423,35 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
             const half2_t pl = __builtin_convertvector(r, half2_t);
             h8[k] = ph.x; h8[k + 1] = ph.y; l8[k] = pl.x; l8[k + 1] = pl.y;
         }
-        yh[p] = h8;
-        yl[p] = l8;
+    };
+    const bool vec = (HW & 3) == 0 && (per & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0;
+    if (vec) {
+        // four consecutive pixels per thread: 8 float4 channel loads, 2 x 4 contiguous 16-byte stores
+        for (long long p = lo + threadIdx.x * 4; p < hi; p += 1024) {
+            f32x4 c4[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c4[k] = *reinterpret_cast<const f32x4*>(xp + (long long)k * HW + p);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = c4[k][q];
+                half8_t h8, l8;
+                one(v, h8, l8);
+                yh[p + q] = h8;
+                yl[p + q] = l8;
+            }
+        }
+    } else {
+        for (long long p = lo + threadIdx.x; p < hi; p += 256) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = xp[(long long)k * HW + p];
+            half8_t h8, l8;
+            one(v, h8, l8);
+            yh[p] = h8;
+            yl[p] = l8;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));

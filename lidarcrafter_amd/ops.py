@@ -286,13 +286,16 @@ class _RangeArena:
             raise RuntimeError("range arena exhausted (more than 4096 live conv layers)")
         slot = self.free.pop()
         self.owner[slot] = weakref.ref(owner)
+        # a recycled slot starts clean: a running maximum left by its previous owner would hide
+        # the new layer's (smaller) values from the poll
+        self.scale[slot] = X_SCALE_DEFAULT
+        with torch.cuda.device(self.device), torch.inference_mode(False):
+            self.buf[slot] = torch.tensor([X_SCALE_DEFAULT, 1.0 / X_SCALE_DEFAULT, 0.0, 0.0], dtype=_F32)
         return slot
 
     def release(self, slot: int) -> None:
         self.owner.pop(slot, None)
-        if self.scale[slot] != X_SCALE_DEFAULT:
-            self._set_scale(slot, X_SCALE_DEFAULT)
-        self.free.append(slot)
+        self.free.append(slot)                   # (re-initialised by the next alloc)
 
     def _set_scale(self, slot: int, scale: float) -> None:
         self.scale[slot] = scale
@@ -351,7 +354,7 @@ def range_poll(device=None, quiet: bool = True):
     if not torch.cuda.is_available():
         return []
     a = _range_arenas.get(_norm_dev(device))
-    if a is None or not a.owner:
+    if a is None:
         return []
     with torch.cuda.device(a.device):
         a.host.copy_(a.buf, non_blocking=False)
