@@ -9,6 +9,7 @@ args = sys.argv[1:]
 lib = cfg = None
 emit = False
 ps = False
+gn = res = False
 shapes = []
 i = 0
 while i < len(args):
@@ -20,6 +21,10 @@ while i < len(args):
         emit = True; i += 1
     elif args[i] == "--ps":
         ps = True; i += 1
+    elif args[i] == "--gn":          # GroupNorm + SiLU fused into the conv's staging
+        gn = True; i += 1
+    elif args[i] == "--res":         # residual operand in the epilogue
+        res = True; i += 1
     else:
         shapes.append(args[i]); i += 1
 if lib:
@@ -58,8 +63,13 @@ for (B, Ci, Co, H, W, ks) in todo:
     xin = x
     if ps and ks == 3 and K.can_presplit(Ci, 8):
         xin = K.groupnorm(x, 8, 1e-6, act_silu=True, split_for=pk)      # pre-split once, outside the graph
+    kw = {}
+    if gn and xin is x:
+        kw["gn_coeffs"] = K.groupnorm_stats(x, 8, 1e-6)
+    if res:
+        kw["res"] = torch.randn(B, Co, H, W, device=dev)
     run = lambda: K.conv2d_ring(xin, pk, w, b, out=out, tile_cfg=cfg or 0, precision="f16x2",
-                                emit_stats=emit)
+                                emit_stats=emit, **kw)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -73,5 +83,5 @@ for (B, Ci, Co, H, W, ks) in todo:
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 20)
     ms = sorted(ts)[2]
-    print(f"B{B} {Ci:4d}->{Co:4d} {H:2d}x{W:4d} k{ks} cfg{cfg or 0}{' ps' if xin is not x else ''}: {ms*1e3:7.1f} us "
+    print(f"B{B} {Ci:4d}->{Co:4d} {H:2d}x{W:4d} k{ks} cfg{cfg or 0}{' ps' if xin is not x else ''}{' gn' if 'gn_coeffs' in kw else ''}{' res' if res else ''}{' emit' if emit else ''}: {ms*1e3:7.1f} us "
           f"{2.0*B*H*W*Co*Ci*ks*ks/ms/1e9:7.1f} TF", flush=True)

@@ -49,6 +49,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #ifndef LC_ABLATE
 #define LC_ABLATE 0   // developer ablation switches (devtools/ablate_conv.sh); 0 in the product
+                      // 1 no split/ds_write, 2 no global loads, 4 no fragment pipelining, 8 no stores,
+                      // 16 no residual loads, 32 no MFMAs
 #endif
 #ifndef LC_PS_ABL
 #define LC_PS_ABL 0   // pre-split kernel ablation: 1 no DMA in the K loop, 2 no MFMAs, 4 no x DMA, 8 no w DMA
@@ -248,6 +250,15 @@ __device__ __forceinline__ void split_pair(float v0, float v1, float xs, h2_t& p
         pl.x = (_Float16)(s0 - (float)a0); pl.y = (_Float16)(s1 - (float)a1);
         return;
     }
+    const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+    const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+    ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    f2_t r; r.x = s0 - h0; r.y = s1 - h1;
+    pl = __builtin_convertvector(r, h2_t);
+}
+// the same rule for values that already carry the scale (fused GroupNorm rows are pre-multiplied)
+__device__ __forceinline__ void split_pair_scaled(float s0, float s1, h2_t& ph, h2_t& pl, float& am) {
+    am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(s0), __builtin_fabsf(s1)));       // v_max3_f32
     const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
     const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
     ph = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
@@ -503,12 +514,23 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-template <class C, bool EMIT_STATS>
+// GNM: 0 = plain input, 1 = GroupNorm(+AdaGN) + SiLU of the input fused into staging, 2 = GroupNorm
+// only.  A template parameter, not a branch: the staging arithmetic must sit in the same basic block
+// as the MFMAs (as a runtime branch it formed its own block, with every LDS latency of the row
+// reads exposed and no MFMA issued meanwhile -- measured r02r: 64->64 @8x32x1024 103 us, 76 us
+// with the staging arithmetic removed).
+template <class C, bool EMIT_STATS, int GNM>
 __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(ConvArgsH a) {
     constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
-    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
+    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, WU = C::WU, NWU = C::NWU;
     constexpr int KS = 2 * HALO + 1;
-    constexpr int NT = C::NT;
+    constexpr int NT = C::NT, NWV = NT / 64;
+    // x staging units: a wave-instruction covers 64 consecutive positions of ONE 8-channel block
+    // (wave-unit j = wave + NWV * i  ->  block j / WPC), so the GroupNorm rows of a unit are the same
+    // for all lanes and the channel block is a scalar.
+    constexpr int PL = XR * XW;                        // positions per 8-channel block
+    constexpr int WPC = (PL + 63) / 64;                // wave-units per block
+    constexpr int NXU = (CB * WPC + NWV - 1) / NWV;    // units per thread
     // every thread always loads NXU / NWU units (no exec-mask branches inside the K loop: a whole
     // chunk is one basic block); units past the end of a plane are stored to one dummy slot.
     constexpr int XUP = XU + 1, WUP = WU + 1;
@@ -559,27 +581,29 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const float out_unscale = a.range->x_unscale * a.wmeta[1];
     float am = 0.0f;
 
-    int x_rc[NXU];         // (row << 16 | column) of the unit inside the staged tile
-    int x_cb8[NXU];        // 8 * channel-block of the unit, or -1 for padding units (CURRENT tile)
+    int x_rc[NXU];         // (row << 16 | column) of the unit inside the staged tile, -1 = no unit
+    int x_cb[NXU];         // 8-channel block of the unit (wave-uniform)
+    int x_ok[NXU];         // CURRENT tile: the unit lies inside the image (else it stages zeros)
     unsigned x_voff[NXU];  // byte offset of the unit's first channel in the sample, OOB marker = pad
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
-        const int e = tid + i * NT;
-        const int cb = e / (XR * XW);
-        const int rem = e - cb * (XR * XW);
-        const int r = rem / XW, c = rem - r * XW;
-        x_rc[i] = e < XU ? ((cb << 28) | (r << 16) | c) : -1;
+        const int j = wave + NWV * i;
+        const int cb = j / WPC;
+        const int loc = (j - cb * WPC) * 64 + lane;
+        const int r = loc / XW, c = loc - r * XW;
+        x_cb[i] = cb < CB ? cb : 0;
+        x_rc[i] = (cb < CB && loc < PL) ? ((r << 16) | c) : -1;
     }
     auto set_tile = [&](int h0t, int w0t) {
 #pragma unroll
         for (int i = 0; i < NXU; ++i) {
-            const int cb = (x_rc[i] >> 28) & 7, r = (x_rc[i] >> 16) & 0xFFF, c = x_rc[i] & 0xFFFF;
+            const int r = (x_rc[i] >> 16) & 0xFFF, c = x_rc[i] & 0xFFFF;
             const int gh = h0t - HALO + r;
             int gw = w0t - HALO + c;
             gw %= W; if (gw < 0) gw += W;
             const bool ok = x_rc[i] >= 0 && gh >= 0 && gh < H;
-            x_voff[i] = ok ? (unsigned)(cb * 8 * HW + gh * W + gw) * 4u : 0xFFFFFFF0u;
-            x_cb8[i] = ok ? 8 * cb : -1;
+            x_voff[i] = ok ? (unsigned)(x_cb[i] * 8 * HW + gh * W + gw) * 4u : 0xFFFFFFF0u;
+            x_ok[i] = ok;
         }
     };
     set_tile(h0, w0);
@@ -594,7 +618,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     }
     const long long w_chunk = (long long)CB * a.Cop;    // unit stride between K chunks
 
-    const bool use_gn = a.gn != nullptr;
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
         for (int i = 0; i < NXU; ++i)
@@ -630,27 +653,54 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     }
     const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
 
-    auto store_tap_x = [](int i) {   // constexpr-foldable
-        const int first = NTAP > NXU + 2 ? NTAP - NXU - 2 : 0;
-        const int t = first + i;
-        return t < NTAP ? t : NTAP - 1;
-    };
     auto store_tap_w = [](int i) {
         const int t = NTAP - 1 - (NWU - 1 - i) / 2;
         return t > 0 ? t : 0;
     };
-    auto store_x = [&](half8* buf, float (&xr)[NXU][8], int i, int ch) {
-        if (LC_ABLATE & 1) { asm volatile("" ::"v"(xr[i][0]), "v"(xr[i][7])); return; }
-        const int e = tid + i * NT;
-        const int d = e < XU ? e : XU;                  // dummy slot for the padding units
-        if (use_gn) {   // fused GroupNorm(+AdaGN)+SiLU of the input; padding units stay exactly 0
-            const int cb8 = x_cb8[i];
-            const f32x4* g = ctab + ch * 16 + (cb8 < 0 ? 0 : cb8);
-            const float keep = cb8 < 0 ? 0.0f : 1.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xr[i][k] = gn_act(xr[i][k], g[k], a.gn_silu) * keep;
+    // fused GroupNorm rows in LDS, per channel PAIR: (A0, A1, B0, B1) with A = rstd * gamma' * xs,
+    // B = (beta' - mu * A') * xs  (x_scale is a power of two: folding it here is exact), so that a
+    // pair of channels costs one broadcast ds_read_b128 and one v_pk_fma_f32;  4 zero quads behind
+    // the table serve the units outside the image (they must stage exact zeros).
+    const float silu_c = -1.4426950408889634f * a.range->x_unscale;   // exp2(silu_c * (y * xs)) = exp(-y)
+    // A unit (8 channels of one position) is staged in four channel-pair steps spread over the taps
+    // of the chunk (2 steps per tap: ~25 VALU in the shadow of 6 MFMAs), then written.
+    half8 st_hi[NXU], st_lo[NXU];
+    auto stage_pair = [&](float (&xr)[NXU][8], int i, int q, int ch) {
+        if (LC_ABLATE & 1) { asm volatile("" ::"v"(xr[i][2 * q]), "v"(xr[i][2 * q + 1])); return; }
+        h2_t ph, pl;
+        if constexpr (GNM != 0) {
+            const f32x4* g = x_ok[i] ? ctab + ch * 8 + x_cb[i] * 4 : ctab + (a.Cgn >> 1);
+            const f32x4 row = g[q];
+            f2_t v = {xr[i][2 * q], xr[i][2 * q + 1]};
+            const f2_t A = {row.x, row.y}, Bv = {row.z, row.w};
+            v = __builtin_elementwise_fma(v, A, Bv);
+            if constexpr (GNM == 1) {
+                const f2_t t = v * silu_c;
+                f2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                e = e + 1.0f;
+                const f2_t rc = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+                v = v * rc;
+            }
+            split_pair_scaled(v.x, v.y, ph, pl, am);
+        } else {
+            split_pair<false>(xr[i][2 * q], xr[i][2 * q + 1], xs, ph, pl, am);
         }
-        split_store(xr[i], xs, buf + d, buf + XUP + d, am);
+        st_hi[i][2 * q] = ph.x; st_hi[i][2 * q + 1] = ph.y;
+        st_lo[i][2 * q] = pl.x; st_lo[i][2 * q + 1] = pl.y;
+    };
+    auto commit_x = [&](half8* buf, int i) {
+        if (LC_ABLATE & 1) return;
+        const int d = x_rc[i] >= 0 ? x_cb[i] * PL + ((x_rc[i] >> 16) & 0xFFF) * XW + (x_rc[i] & 0xFFFF) : XU;
+        buf[d] = st_hi[i];
+        buf[XUP + d] = st_lo[i];
+    };
+    constexpr int NSTEP = 4 * NXU;
+    constexpr int SPT = NTAP == 1 ? NSTEP : ((NSTEP + NTAP - 2) / (NTAP - 1) > 2 ? (NSTEP + NTAP - 2) / (NTAP - 1) : 2);
+    auto step_tap = [](int st) {   // constexpr-foldable: the steps end one tap before the last
+        if (NTAP == 1) return 0;
+        const int ntaps = (NSTEP + SPT - 1) / SPT;
+        const int first = NTAP - 1 - ntaps > 0 ? NTAP - 1 - ntaps : 0;
+        return first + st / SPT;
     };
     auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
         if (LC_ABLATE & 1) { asm volatile("" ::"v"(wr[2 * i]), "v"(wr[2 * i + 1])); return; }
@@ -694,11 +744,22 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
             // (A finer sched_group_barrier interleave was measured 3-10 % slower than letting
             // hipcc schedule each tap region on its own.)
 #pragma unroll
-            for (int i = 0; i < NXU; ++i)
-                if (tap == store_tap_x(i)) store_x(nxt, xr, i, chn);
+            for (int st = 0; st < NSTEP; ++st)
+                if (tap == step_tap(st)) {
+                    stage_pair(xr, st >> 2, st & 3, chn);
+                    if ((st & 3) == 3) commit_x(nxt, st >> 2);
+                }
 #pragma unroll
             for (int i = 0; i < NWU; ++i)
                 if (tap == store_tap_w(i)) store_w(nxt, wr, i);
+            if (LC_ABLATE & 32) {   // no MFMAs: keep the fragments alive
+#pragma unroll
+                for (int i = 0; i < C::TCO_; ++i) asm volatile("" ::"v"(ah[s][i]), "v"(al[s][i]));
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j) asm volatile("" ::"v"(bh[s][j]), "v"(bl[s][j]));
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             if (LC_F16X2_TERMS & 2) {
 #pragma unroll
                 for (int i = 0; i < C::TCO_; ++i)
@@ -731,7 +792,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     // prologue: chunk 0 -> cur
     load_x(xr, 0);
     load_w(wr, 0);
-    if (use_gn) {   // rows of the fused input norm, derived while the chunk-0 loads are in flight
+    if constexpr (GNM != 0) {   // rows of the fused input norm, derived while the chunk-0 loads are in flight
         if (a.gs.partials) {
             for (int i = tid; i < a.Cgn; i += NT) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
         } else if (a.seg[0].p) {
@@ -740,10 +801,34 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
             const f32x4* g = a.gn + (long long)b * a.Cgn;
             for (int i = tid; i < a.Cgn; i += NT) ctab[i] = g[i];
         }
-        __syncthreads();                                // ctab visible
+        __syncthreads();                                // (mu, A, B, 0) rows visible
+        // ... repacked in place into the pair quads the staging code reads
+        constexpr int NQ = (GN_MAX_C / 2 + NT - 1) / NT;
+        const int npair = a.Cgn >> 1;
+        f32x4 qd[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int p = tid + k * NT;
+            if (p < npair) {
+                const f32x4 r0 = ctab[2 * p], r1 = ctab[2 * p + 1];
+                qd[k] = f32x4{r0.y * xs, r1.y * xs, fmaf(-r0.x, r0.y, r0.z) * xs, fmaf(-r1.x, r1.y, r1.z) * xs};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int p = tid + k * NT;
+            if (p < npair) ctab[p] = qd[k];
+        }
+        if (tid < 4) ctab[npair + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < NXU; ++i) store_x(cur, xr, i, 0);
+    for (int i = 0; i < NXU; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_pair(xr, i, q, 0);
+        commit_x(cur, i);
+    }
 #pragma unroll
     for (int i = 0; i < NWU; ++i) store_w(cur, wr, i);
     __syncthreads();
@@ -773,7 +858,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    res_r[i][j][r] = (rb && pok && co < a.Co) ? rb[(long long)co * HW + poff] : 0.0f;
+                    res_r[i][j][r] = (rb && pok && co < a.Co && !(LC_ABLATE & 16)) ? rb[(long long)co * HW + poff] : 0.0f;
                 }
         }
     };
@@ -820,12 +905,12 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
                     if constexpr (!EMIT_STATS) {
                         if (pok && co < a.Co) {
                             const float v = (acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r];
-                            epi_store(&yb[(long long)co * HW + poff], v * a.out_scale);
+                            if (!(LC_ABLATE & 8) || v == 1.2345e-30f) epi_store(&yb[(long long)co * HW + poff], v * a.out_scale);
                         }
                     } else {
                         const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
                                         a.out_scale;
-                        if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
+                        if (pok && co < a.Co && (!(LC_ABLATE & 8) || v == 1.2345e-30f)) epi_store(&yb[(long long)co * HW + poff], v);
                         const int m = r >> 2;
                         if (j == 0 && (r & 3) == 0) {
                             st_p[i][m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
@@ -1245,8 +1330,14 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
             return LC_EUNSUP;
         }
     }
-    if (a.ostats) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, true>), grid, dim3(C::NT), 0, st, a);
-    else hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, false>), grid, dim3(C::NT), 0, st, a);
+    const int gnm = a.gn ? (a.gn_silu ? 1 : 2) : 0;
+#define LC_PIPE_LAUNCH(E, G) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, E, G>), grid, dim3(C::NT), 0, st, a)
+    if (a.ostats) {
+        if (gnm == 1) LC_PIPE_LAUNCH(true, 1); else if (gnm == 2) LC_PIPE_LAUNCH(true, 2); else LC_PIPE_LAUNCH(true, 0);
+    } else {
+        if (gnm == 1) LC_PIPE_LAUNCH(false, 1); else if (gnm == 2) LC_PIPE_LAUNCH(false, 2); else LC_PIPE_LAUNCH(false, 0);
+    }
+#undef LC_PIPE_LAUNCH
     return lc_launch_status();
 }
 
@@ -1432,7 +1523,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     }
     a.tpb = 0;
     if (tile_cfg >= 100) { a.tpb = tile_cfg / 100; tile_cfg %= 100; }   // cfg = tpb*100 + tile id
-    if (a.gn && (a.Cgn < (Ci + 15) / 16 * 16 || a.Cgn > GN_MAX_C)) return LC_EINVAL;
+    if (a.gn && (a.Cgn < (Ci + 15) / 16 * 16 || a.Cgn > GN_MAX_C || (a.Cgn & 1))) return LC_EINVAL;
     // A 1x1 conv has no spatial structure: fold the contiguous H*W plane into rows of 64 pixels so
     // that the 2-row tiles are fully used whatever the caller's aspect ratio is (a Conv1d over L
     // tokens arrives as H = 1, W = L and would leave every second tile row empty).
