@@ -803,22 +803,7 @@ def test_transform_points_bit_exact(dev, golden):
     assert np.abs(w - g["warp_lidar64"][3]).max() < 1e-5
 
 
-def _temporal_scene(seed, H=32, W=1024, n_pts=30000, K_=5):
-    """First-frame dict like sample_and_save_temporal.py:281-289, built with the oracle."""
-    from lidarcrafter_amd.testing import synth_boxes, synth_points, synth_temporal_inputs
-    from oracle import temporal as OT
-
-    trajs, _ = synth_temporal_inputs(seed, K=K_)
-    pts = synth_points(n_pts, seed=seed + 100)
-    pts[:, 3] = np.floor(pts[:, 3])
-    boxes = synth_boxes(K_, pts, seed=seed + 200)
-    boxes[:, 3:6] += 3.0                                   # big enough to own some pixels
-    names = ["ego"] + [OT.CLASS_NAMES[i % 8] for i in range(K_)]
-    gt_boxes = np.concatenate([np.zeros((1, 7), np.float32), boxes]).astype(np.float64)
-    item = OT.custom_item(pts, gt_boxes, names, H, W)
-    first = dict(gt_fut_trajs=trajs, xyz=item["xyz"], reflectance=item["reflectance"],
-                 gt_boxes=gt_boxes, gt_names=names, condition_mask=item["condition_mask"])
-    return first, pts, item
+from tests._scenes import temporal_scene as _temporal_scene  # noqa: E402
 
 
 def test_custom_dataset_item_vs_unpinned_restatement(dev):
@@ -877,6 +862,37 @@ def test_temporal_frame_glue_vs_unpinned_restatement(dev, seed):
         rcur = OT.delete_fg_points(rcomb, rfut_boxes[:, t])
         assert np.array_equal(cur.cpu().numpy(), rcur), t
         assert 0 < cur.shape[0] < comb.shape[0]
+
+
+def test_temporal_glue_vs_reference_golden(dev, golden):
+    """Device get_temporal_boxes_3d / delete_fg_points vs outputs of the REFERENCE's own
+    pipe_related.py (tests/golden/pipe.npz): identical point selections and order; coordinates within
+    one float32 ulp (the device keeps float32 rows and rounds once, the reference carries float64
+    between stages -- DESIGN section 5b)."""
+    import lidargen  # noqa: F401
+    from lidargen.utils import temporal as T
+
+    g = golden("pipe")
+    for seed in (0, 1):
+        first, _, _ = _temporal_scene(seed, H=8, W=256, n_pts=6000)
+        t = f"s{seed}_"
+        dfirst = dict(first)
+        for k in ("xyz", "reflectance", "condition_mask"):
+            dfirst[k] = torch.from_numpy(np.ascontiguousarray(first[k])).to(dev)
+        bg, fut_bg, boxes, fut_boxes, Ts, obj_pts, obj_int = T.get_temporal_boxes_3d(dfirst, M=None)
+        assert np.array_equal(bg.cpu().numpy(), g[t + "bg"])
+        assert np.array_equal(np.asarray(fut_boxes), g[t + "fut_boxes"]) and np.array_equal(np.asarray(Ts), g[t + "Ts"])
+        assert np.abs(fut_bg[0].cpu().numpy() - g[t + "fut_bg_first"]).max() <= 7.7e-6
+        assert np.abs(fut_bg[-1].cpu().numpy() - g[t + "fut_bg_last"]).max() <= 7.7e-6
+        assert np.array_equal(np.array([p.shape[0] for p in obj_pts]), g[t + "obj_n"])
+        assert np.abs(torch.cat(obj_pts).cpu().numpy() - g[t + "obj_pts"]).max() <= 1e-6
+        assert np.array_equal(torch.cat(obj_int).cpu().numpy(), g[t + "obj_int"])
+        comb = torch.cat([fut_bg[0], bg], dim=0).contiguous()
+        kept = T.delete_fg_points(comb, g[t + "fut_boxes"][:, 0])
+        assert kept.shape[0] == g[t + "delete_fg"].shape[0]
+        assert np.abs(kept.cpu().numpy() - g[t + "delete_fg"]).max() <= 7.7e-6
+        m9 = T.get_temporal_boxes_3d(dfirst, M=9)
+        assert np.array_equal(np.asarray(m9[3]), g[t + "M9_fut_boxes"]) and np.array_equal(np.asarray(m9[4]), g[t + "M9_Ts"])
 
 
 def test_generate_sequence_device_loop(dev):
