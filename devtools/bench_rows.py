@@ -218,6 +218,33 @@ def train_step(dev, B):
             "note": "forward + backward + AdamW, exact-fp32 MFMA convolutions (LC_TRAIN_CONV_PRECISION=f32)"}
 
 
+def train_step_cond(dev, B):
+    """One training step of the layout-conditioned denoiser + layout encoder (box-layout-v6, 70 M
+    parameters), tools/train/train_lidm_cond.py:259-322 at batch B: ddpm(batch) -> backward -> AdamW."""
+    from lidarcrafter_amd.testing import seeded_fill, synth_layout_batch
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model, _ = inference.load_model_duffusion_training(C["nuscenes-box-layout-v6"]())
+    seeded_fill(model, salt=200), seeded_fill(ddpm.condition_model, salt=201)
+    ddpm = ddpm.train().to(dev)
+    opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(B, 32, 1024, seed=53).items()}
+    batch["x_0"] = torch.randn(B, 2, 32, 1024, device=dev).clamp(-1, 1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ddpm(batch)
+        loss.backward()
+        opt.step()
+
+    dt = timed(step, 5, warm=2)
+    flop = 3 * B * GFLOP["cond32"] * 1e9
+    return {"batch": B, "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2),
+            "algorithmic_tflops": round(flop / dt / 1e12, 1),
+            "note": "denoiser + layout encoder, forward + backward + AdamW, exact-fp32 MFMA convolutions, dropout as configured"}
+
+
 def object_branch(dev, n_obj, steps):
     """Foreground-object branch: `steps` DDPM steps of PointUNet over n_obj x [1024, 4] point sets."""
     from lidarcrafter_amd.testing import seeded_fill, synth_object_batch, synth_text_features
@@ -259,21 +286,32 @@ def voxel_scatter(dev, n_sweeps, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated row names (default: all)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     out = {"device": torch.cuda.get_device_name(0)}
-    out["uncond_32x1024"] = [uncond(dev, B, (32, 1024), 20 if B <= 8 else 8, "uncond32")
-                             for B in ((1, 8) if args.quick else (1, 2, 8, 32))]
-    out["cond_layout_v6_32x1024"] = [cond(dev, B, 10) for B in ((8,) if args.quick else (1, 8))]
-    if not args.quick:
-        out["uncond_64x2048"] = [uncond(dev, 4, (64, 2048), 6, "uncond64")]
-    out["temporal_sequence_32x1024"] = [sequence(dev, 2, 5, 16 if args.quick else 32)]
-    out["pipeline_metrics_c5_shape"] = [pipeline_metrics(dev, 8, 1 if args.quick else 2, 8)]
-    out["train_step_c2"] = [train_step(dev, B) for B in ((2,) if args.quick else (2, 8))]
-    out["object_branch"] = [object_branch(dev, 10, 256)]
-    out["voxel_scatter"] = [voxel_scatter(dev, 16, 34720)]
-    out["projection"] = [projection(dev, N) for N in (34720, 131072, 1 << 22)]
-    out["points_in_boxes_mask"] = [pib(dev, N, nb) for N, nb in ((34720, 13), (1 << 22, 13))]
+    q = args.quick
+    rows = {
+        "uncond_32x1024": lambda: [uncond(dev, B, (32, 1024), 20 if B <= 8 else 8, "uncond32")
+                                   for B in ((1, 8) if q else (1, 2, 8, 32))],
+        "cond_layout_v6_32x1024": lambda: [cond(dev, B, 10) for B in ((8,) if q else (1, 8))],
+        "uncond_64x2048": lambda: [] if q else [uncond(dev, 4, (64, 2048), 6, "uncond64")],
+        "temporal_sequence_32x1024": lambda: [sequence(dev, 2, 5, 16 if q else 32)],
+        "pipeline_metrics_c5_shape": lambda: [pipeline_metrics(dev, 8, 1 if q else 2, 8)],
+        "train_step_c2": lambda: [train_step(dev, B) for B in ((2,) if q else (2, 8))],
+        "train_step_c3": lambda: [train_step_cond(dev, B) for B in ((2,) if q else (2, 8))],
+        "object_branch": lambda: [object_branch(dev, 10, 256)],
+        "voxel_scatter": lambda: [voxel_scatter(dev, 16, 34720)],
+        "projection": lambda: [projection(dev, N) for N in (34720, 131072, 1 << 22)],
+        "points_in_boxes_mask": lambda: [pib(dev, N, nb) for N, nb in ((34720, 13), (1 << 22, 13))],
+    }
+    only = [r for r in args.only.split(",") if r]
+    for name, fn in rows.items():
+        if only and name not in only:
+            continue
+        res = fn()
+        if res:
+            out[name] = res
     print(json.dumps(out, indent=1))
 
 

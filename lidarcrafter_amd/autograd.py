@@ -247,3 +247,108 @@ class _LinearAsConv:
         self.weight, self.bias = weight[:, :, None, None], bias
         self.__dict__["_train_packed"] = owner.__dict__.setdefault(
             "_train_packed_" + tag, {"fwd": K.PackedConv("train.fwd"), "bwd": K.PackedConv("train.bwd")})
+
+
+# ------------------------------------------------------------------------------------------------
+def _tok(x3):
+    """[B, C, L] tokens as the [B, C, 1, L] image the conv / GroupNorm Functions take."""
+    return x3.unsqueeze(2)
+
+
+def _gn_tok(module, x3, **kw):
+    return group_norm(module, _tok(x3), **kw).squeeze(2)
+
+
+def _conv_tok(module, x3):
+    """1x1 projection of channel-major tokens: the MFMA conv for image-sized token sets, a torch
+    conv1d for the 13-token layout operands (a few kFLOP)."""
+    if x3.shape[-1] < 64:
+        return F.conv1d(x3, module.weight, module.bias)
+    return conv(module, _tok(x3)).squeeze(2)
+
+
+def layout_unet_v1_forward(m, x: torch.Tensor, cond_dict: dict) -> torch.Tensor:
+    """Differentiable forward of lidargen.models.unets.LayoutUnetV1 (reference layout_unet_v1.py:
+    ResBlock :143-249, ObjectAwareCrossAttention :416-532, forward :866-902) -- the graph
+    `accelerator.backward(loss)` of tools/train/train_lidm_cond.py:259-322 differentiates, including
+    the path into the layout encoder's outputs (xf_proj, xf_out, class / box embeddings).  Ring
+    convolutions, GroupNorm(+scale/shift)(+SiLU), FIR resampling and the image-token projections are
+    the HIP Functions above; the joint image|layout attention core and the 13-token layout
+    operands are differentiable torch ops on the device."""
+    from lidarcrafter_amd.lidargen.models.unets import layout_unet_v1 as L
+
+    lay = cond_dict["other_condition"]
+    B, _, H, W = x.shape
+    t = cond_dict["time_condition"]
+    if t.dim() == 0:
+        t = t[None].repeat_interleave(B, dim=0)
+    te = m.time_embed
+    emb = F.linear(F.silu(F.linear(te[0](t.float()), te[1].weight, te[1].bias)), te[3].weight,
+                   te[3].bias) + lay["xf_proj"].float()
+    with torch.no_grad():
+        enc = m.coords_encoding(m.coords)
+    parts = [x.float()]
+    if "concat_cond" in lay:
+        parts.append(lay["concat_cond"].float())
+    parts.append(enc.expand(B, -1, -1, -1))
+    h = torch.cat(parts, dim=1)
+
+    def res_block(rb, x):
+        a = group_norm(rb.in_layers[0], x, act=True)
+        if rb.updown:
+            up = rb.op.up == 2
+            a, x = resample(a, up), resample(x, up)
+        h = conv(rb.in_layers[2], a)
+        e = F.linear(F.silu(emb), rb.emb_layers[1].weight, rb.emb_layers[1].bias)
+        C = rb.out_channels
+        h = group_norm(rb.out_layers[0], h, act=True, scale=e[:, :C], shift=e[:, C:])
+        h = F.dropout(h, rb.dropout, training=rb.training)
+        h = conv(rb.out_layers[3], h)
+        sk = x if isinstance(rb.skip_connection, torch.nn.Identity) else conv(rb.skip_connection, x)
+        return sk + h
+
+    def attention(at, x):
+        B_, C, H_, W_ = x.shape
+        L1 = H_ * W_
+        heads = at.num_heads
+        d = C // heads
+        xs = x.reshape(B_, C, L1)
+        qkv = _conv_tok(at.qkv_projector, _gn_tok(at.norm_for_qkv, xs))
+        img = lay[f"image_patch_bbox_embedding_for_resolution{at.resolution}"].float()
+        pos_img = _gn_tok(at.norm_for_image_patch_positional_embedding,
+                          _conv_tok(at.layout_position_embedding_projector, img.contiguous()))
+        pos_lay = _gn_tok(at.norm_for_layout_positional_embedding,
+                          _conv_tok(at.layout_position_embedding_projector, lay["obj_bbox_embedding"].float()))
+        content = (lay["xf_out"].float() + _gn_tok(at.norm_for_obj_class_embedding,
+                                                   lay["obj_class_embedding"].float())) * 0.5
+        kv = _conv_tok(at.layout_content_embedding_projector, content)
+        hv = lambda t_: t_.reshape(B_, heads, d, -1)
+        q, k, v = (hv(t_) for t_ in qkv.split(C, dim=1))
+        pi, pl, kl, vl = hv(pos_img), hv(pos_lay), hv(kv[:, :C]), hv(kv[:, C:])
+        s2 = 1.0 / (2 * d) ** 0.5                     # (q s)(k s) with s = (2d)^-1/4
+        # content and positional halves of the concatenated operands contribute separate products
+        s_img = (torch.einsum("bhct,bhcs->bhts", q, k) + torch.einsum("bhct,bhcs->bhts", pi, pi)) * s2
+        s_lay = (torch.einsum("bhct,bhcs->bhts", q, kl) + torch.einsum("bhct,bhcs->bhts", pi, pl)) * s2
+        w = torch.cat([s_img, s_lay], dim=-1).softmax(-1)
+        a = torch.einsum("bhts,bhcs->bhct", w[..., :L1], v) + torch.einsum("bhts,bhcs->bhct", w[..., L1:], vl)
+        out = xs + _conv_tok(at.proj_out, a.reshape(B_, C, L1))
+        return out.reshape(B_, C, H_, W_)
+
+    def seq(blk, h):
+        for layer in blk:
+            if isinstance(layer, L.ResBlock):
+                h = res_block(layer, h)
+            elif isinstance(layer, L.ObjectAwareCrossAttention):
+                h = attention(layer, h)
+            else:
+                h = conv(layer, h)
+        return h
+
+    hs = []
+    for blk in m.input_blocks:
+        h = seq(blk, h)
+        hs.append(h)
+    h = seq(m.middle_block, h)
+    for blk in m.output_blocks:
+        h = seq(blk, torch.cat([h, hs.pop()], dim=1))
+    return conv(m.out[2], group_norm(m.out[0], h, act=True))

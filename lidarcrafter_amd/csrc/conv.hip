@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(ConvArgs a) {
                 const int c4 = e - row * (BN / 4);
                 const int tap = row / CK, ci = row - tap * CK;
                 const float* p = a.wp + ((long long)tap * a.Cip + (c0 + ci)) * a.Cop + co0 + c4 * 4;
-                wr[i] = *reinterpret_cast<const f32x4*>(p);
+                // packed rows are padded to 64 output channels: the upper half of a 128-channel
+                // block may lie past the row (Co % 128 in (0, 64]) -- its outputs are never stored
+                wr[i] = co0 + c4 * 4 < a.Cop ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };

@@ -4,6 +4,8 @@ p_step :206-253, sample :255-281, inpaint :283-353, p_loss/forward :414-456).
 The condition dict is built ONCE per batch; per step only `time_condition` changes."""
 from __future__ import annotations
 
+import contextlib
+
 from typing import Literal
 
 import torch
@@ -109,8 +111,13 @@ class CondContinuousTimeGaussianDiffusion(continuous_time.ContinuousTimeGaussian
         x_0 = input_dict["x_0"]
         loss_mask = torch.ones_like(x_0) if loss_mask is None else loss_mask
         x_t, noise = self.q_step_from_x_0(x_0, steps)
-        condition = self.get_network_condition(steps, input_dict)
-        with torch.no_grad():
+        from lidarcrafter_amd import autograd as AG
+
+        # grad mode on + trainable parameters: the denoiser (and the layout encoder feeding it) build
+        # an autograd graph, `ddpm(batch).backward()` works as in tools/train/train_lidm_cond.py
+        train = AG.training_active(self.model) or AG.training_active(self.condition_model)
+        with (contextlib.nullcontext() if train else torch.no_grad()):
+            condition = self.get_network_condition(steps, input_dict)
             prediction = self._predict_cond(x_t, condition)
         return self._masked_loss(prediction, self.get_target(x_0, steps, noise), loss_mask, steps)
 

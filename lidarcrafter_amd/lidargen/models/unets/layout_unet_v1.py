@@ -22,6 +22,7 @@ import torch
 import torch as th
 import torch.nn as nn
 
+from lidarcrafter_amd import autograd as AG
 from lidarcrafter_amd import ops as K
 
 from . import encoding, ops
@@ -345,6 +346,9 @@ class LayoutUnetV1(nn.Module):
     @K.range_checked
     def forward(self, x, cond_dict, time_features=None):
         lay = cond_dict["other_condition"]
+        if time_features is None and AG.training_active(self, x, lay.get("xf_proj"), lay.get("xf_out")):
+            # training: the autograd graph over the HIP kernels (lidarcrafter_amd/autograd.py)
+            return AG.layout_unet_v1_forward(self, x, cond_dict)
         B, cx, H, W = x.shape
         if time_features is None:
             t = cond_dict["time_condition"]

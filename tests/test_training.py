@@ -140,3 +140,70 @@ def test_unet_loss_gradients_and_one_step(dev):
         l1 = ((m(x_t.to(dev), lam[:, 0, 0, 0].to(dev)) - noise.to(dev)) ** 2).mean()
     assert torch.isfinite(l1)
     print(f"worst parameter-gradient rel-L2 {worst:.2e}")
+
+
+def test_layout_unet_loss_gradients_and_one_step(dev):
+    """The layout-conditioned training graph (tools/train/train_lidm_cond.py:259-322): gradients of
+    every parameter of the reduced LayoutUnetV1 AND of the layout encoder feeding it (xf_proj into
+    the time embedding, xf_out / class / box embeddings into the object-aware attention) vs
+    autograd of the oracle; then `ddpm(batch)` + AdamW as the script calls it."""
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from oracle import denoiser as D
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    m, enc = build_cond_pair((8, 64), 8, 32)       # eval(): dropout off, graph still built (grad mode)
+    m, enc = m.to(dev), enc.to(dev)
+    batch_c = synth_layout_batch(2, 8, 64, seed=51)
+    batch = {k: v.to(dev) for k, v in batch_c.items()}
+    x_t = seeded_randn(2, 2, 8, 64, seed=33)
+    noise = seeded_randn(2, 2, 8, 64, seed=34)
+    lam = torch.tensor([-1.5, 2.0])
+    cond = enc(batch)
+    pred = m(x_t.to(dev), {"time_condition": lam.to(dev), "other_condition": cond})
+    assert pred.requires_grad
+    loss = ((pred - noise.to(dev)) ** 2).mean()
+    loss.backward()
+
+    def leaves(mod):
+        return {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and k.split(".")[-1]
+                                                           not in ("kernel", "coords", "freqs", "phase"))
+                for k, v in mod.state_dict().items()}
+
+    sd, sde = leaves(m), leaves(enc)
+    enc_fwd = getattr(D.layout_encoder_forward, "__wrapped__", D.layout_encoder_forward)
+    net_fwd = getattr(D.layout_unet_v1_forward, "__wrapped__", D.layout_unet_v1_forward)
+    rcond = enc_fwd(sde, batch_c, feature_map_size=[8, 64], resolution_to_attention=[4, 8])
+    ref = ((net_fwd(sd, x_t, lam, rcond, image_size=8, model_channels=32) - noise) ** 2).mean()
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    worst = 0.0
+    # a conv bias in front of a GroupNorm whose groups hold ONE channel (C = 32) has an exactly zero
+    # gradient: both sides return rounding noise there, so the bound carries an absolute floor
+    # relative to the largest parameter gradient
+    top = max(float(v.grad.norm()) for v in list(sd.values()) + list(sde.values()) if v.grad is not None)
+    for mod, ref_sd, tag in ((m, sd, "unet"), (enc, sde, "encoder")):
+        for k, p in mod.named_parameters():
+            if ref_sd[k].grad is None:       # parameters the configuration does not use (e.g. 3-D mask embedding)
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (tag, k)
+                continue
+            assert p.grad is not None, (tag, k)
+            gr = ref_sd[k].grad.double()
+            err = float((p.grad.detach().cpu().double() - gr).norm())
+            assert err < 3e-4 * float(gr.norm()) + 1e-6 * top, (tag, k, err, float(gr.norm()), top)
+            if float(gr.norm()) > 1e-4 * top:
+                worst = max(worst, err / float(gr.norm()))
+    print(f"worst parameter-gradient rel-L2 {worst:.2e}")
+    # the script's call: ddpm(batch) draws timesteps / noise itself; AdamW over denoiser + encoder
+    ddpm = CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").to(dev)
+    opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)
+    opt.zero_grad()
+    item = dict(batch)
+    item["x_0"] = seeded_randn(2, 2, 8, 64, seed=35).clamp(-1, 1).to(dev)
+    l0 = ddpm(item)
+    l0.backward()
+    used = [p for p in ddpm.parameters() if p.grad is not None]
+    assert len(used) > 200 and all(torch.isfinite(p.grad).all() for p in used)
+    opt.step()
+    with torch.no_grad():
+        assert torch.isfinite(ddpm(item))
