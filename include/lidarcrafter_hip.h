@@ -84,6 +84,13 @@ int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int
 typedef struct lc_conv_range {
     float x_scale, x_unscale, amax_scaled, reserved;
 } lc_conv_range;
+/* The record of a tensor measured on the device: max |x| over B samples of n floats (sample stride
+ * x_bs) -> x_scale = the power of two with max|x| * x_scale in [2^12, 2^13), amax_scaled = 0.  Two
+ * tiny launches, no host synchronisation; `reserved` is the reduction's scratch word (0 between
+ * calls).  Training uses it right before every f16x2 conv (activations in the forward, gradients in
+ * the backward: lidarcrafter_amd/autograd.py), where a poll-and-repeat protocol is not available. */
+int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t n, lc_conv_range* range,
+                         lc_stream_t s);
 /* Producer-side GroupNorm statistics of one channel segment: the entries a conv wrote through
  * gn_ostats_out (below), consumed by lc_groupnorm_apply_os or by the next conv's fused input norm. */
 typedef struct lc_oct_stats {
@@ -298,7 +305,7 @@ int lc_add_scale(const float* a, int64_t a_bs, const float* b, int64_t b_bs, flo
  * with respect to the weights and bias is lc_conv2d_ring_wgrad:
  *   dW[co][ci][ky][kx] (+)= sum_{b,h,w} dY[b,co,h,w] * Xpad[b,ci,h+ky-1,w+kx-1],  db[co] (+)= sum dY
  * fp32 matrix cores (exact fp32 products, fp32 accumulation), deterministic two-stage reduction;
- * scratch: lc_conv2d_ring_wgrad_scratch_elems floats; dbias may be NULL; accumulate != 0 adds to
+ * scratch: lc_conv2d_ring_wgrad_scratch_elems floats (8-byte aligned); dbias may be NULL; accumulate != 0 adds to
  * dw / dbias (gradient accumulation), 0 overwrites.
  *
  * GroupNorm (+affine) (+AdaGN scale/shift) (+SiLU), forward y = silu?(((x-mu) rstd g + be)(1+sc) + sf):

@@ -59,6 +59,7 @@ SIGNATURES = {
                                           i32, i32, f32, i32, vp, vp]),
     "lc_conv2d_ring_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32,
                                           f32, i32, vp, vp, i32, vp, vp, vp]),
+    "lc_range_from_tensor": (i32, [vp, i64, i32, i64, vp, vp]),
     "lc_splitk_stats_slots": (i64, [i32, i32]),
     "lc_splitk_reduce": (i32, [vp, i32, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, vp, vp]),
     "lc_conv2d_ring_f16x2_stats_slots": (i64, [i32, i32, i32, i32, i32, i32, i32]),

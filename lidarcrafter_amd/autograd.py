@@ -34,9 +34,11 @@ import torch.nn.functional as F
 from . import ops as K
 from ._lib import check, lib
 
-# arithmetic of the convolutions inside the training graph: "f32" = exact-fp32 MFMA kernels
-# (gradients of any magnitude are safe), "f16x2" = the split kernels (range-checked like inference)
-TRAIN_CONV_PRECISION = os.environ.get("LC_TRAIN_CONV_PRECISION", "f32")
+# arithmetic of the forward / dX convolutions inside the training graph: "f16x2" = the split kernels
+# (fp32-class accuracy; the pre-scale of every operand -- activation or gradient -- is measured on
+# the device right before its conv, K.range_from_tensor), "f32" = exact-fp32 MFMA kernels.
+# The weight-gradient kernel is exact fp32 either way.
+TRAIN_CONV_PRECISION = os.environ.get("LC_TRAIN_CONV_PRECISION", "f16x2")
 
 
 def training_active(module: torch.nn.Module, *tensors) -> bool:
@@ -58,6 +60,8 @@ class ConvRing(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, holder):
         x = _c4(x)
+        if TRAIN_CONV_PRECISION == "f16x2":
+            K.range_from_tensor(x, holder["fwd"])
         y = K.conv2d_ring(x, holder["fwd"], weight, bias, precision=TRAIN_CONV_PRECISION)
         ctx.save_for_backward(x, weight)
         ctx.holder, ctx.has_bias = holder, bias is not None
@@ -72,6 +76,8 @@ class ConvRing(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [Ci, Co, ks, ks]
+            if TRAIN_CONV_PRECISION == "f16x2":
+                K.range_from_tensor(dy, ctx.holder["bwd"])
             dx = K.conv2d_ring(dy, ctx.holder["bwd"], wt, None, precision=TRAIN_CONV_PRECISION)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)

@@ -1410,16 +1410,31 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     return 3;
 }
 
+// One atomicMax per BLOCK, and only when the block's maximum beats what is already published
+// (thousands of same-address atomics serialise in L2: 150 us per call in the first version).
+__device__ __forceinline__ void block_amax_publish(float am, unsigned* slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    __shared__ float wmax[16];
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wmax[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, wmax[i]);
+        const unsigned bits = __float_as_uint(m);
+        if (m > 0.0f && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(slot, bits);
+    }
+}
+
 // max |w| of the tensor -> wmeta[2] (atomicMax on the bit pattern; wmeta zeroed before)
 __global__ void weight_amax_kernel(const float* __restrict__ w, long long n, float* wmeta) {
     float am = 0.0f;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x)
         am = fmaxf(am, fabsf(w[e]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-    if ((threadIdx.x & 63) == 0 && am > 0.0f)
-        atomicMax(reinterpret_cast<unsigned*>(wmeta + 2), __float_as_uint(am));
+    block_amax_publish(am, reinterpret_cast<unsigned*>(wmeta + 2));
 }
 
 // the weight pre-scale from max|w| (see lc_pack_conv_weight_f16x2 in the header)
@@ -1475,6 +1490,63 @@ extern "C" int lc_pack_conv_weight_f16x2(const float* w, void* wp_hi, void* wp_l
     hipLaunchKernelGGL(weight_amax_kernel, dim3(ablocks), dim3(256), 0, lc_s(s), w, nw, wmeta);
     hipLaunchKernelGGL(pack_weight_h_kernel, dim3(blocks), dim3(256), 0, lc_s(s), w,
                        (_Float16*)wp_hi, (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop, wmeta);
+    return lc_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Range record of a tensor derived ON THE DEVICE (training: activations and gradients change
+// magnitude from step to step, and a backward pass cannot be repeated from inside autograd, so
+// the scale is measured just before the conv that consumes the tensor -- one extra read of it,
+// no host synchronisation, the record is exact for the very tensor the kernel will split).
+__global__ void tensor_amax_kernel(const float* __restrict__ x, long long x_bs, long long n, int B,
+                                   lc_conv_range* rg) {
+    float am = 0.0f;
+    const long long n4 = n >> 2;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float* p = x + b * x_bs;
+        if ((reinterpret_cast<unsigned long long>(p) & 15) == 0) {
+            const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+            for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4;
+                 e += (long long)gridDim.x * blockDim.x) {
+                const f32x4 v = p4[e];
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+            for (long long e = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
+                 e += (long long)gridDim.x * blockDim.x)
+                am = fmaxf(am, fabsf(p[e]));
+        } else {
+            for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
+                 e += (long long)gridDim.x * blockDim.x)
+                am = fmaxf(am, fabsf(p[e]));
+        }
+    }
+    block_amax_publish(am, reinterpret_cast<unsigned*>(&rg->reserved));   // NaN / 0 never win; inf is handled below
+}
+__global__ void range_set_kernel(lc_conv_range* rg) {
+    const float amax = rg->reserved;
+    float sc = X_PRESCALE_DEFAULT;
+    if (amax > 0.0f && amax < 3.0e38f) {
+        int e;
+        frexpf(amax, &e);                                   // amax = m * 2^e, m in [0.5, 1)
+        int k = 13 - e;
+        k = k < -120 ? -120 : (k > 120 ? 120 : k);
+        sc = ldexpf(1.0f, k);                               // amax * scale in [2^12, 2^13)
+    }
+    rg->x_scale = sc;
+    rg->x_unscale = 1.0f / sc;
+    rg->amax_scaled = 0.0f;
+    rg->reserved = 0.0f;
+}
+
+extern "C" int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t n, lc_conv_range* range,
+                                    lc_stream_t s) {
+    if (!x || !range || B <= 0 || n <= 0) return LC_EINVAL;
+    long long bx = (n / 4 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 512 ? 512 : bx);
+    const int by = B < 8 ? B : 8;
+    hipLaunchKernelGGL(tensor_amax_kernel, dim3((unsigned)bx, by), dim3(256), 0, lc_s(s), x, (long long)x_bs,
+                       (long long)n, B, range);
+    hipLaunchKernelGGL(range_set_kernel, dim3(1), dim3(1), 0, lc_s(s), range);
     return lc_launch_status();
 }
 

@@ -574,6 +574,19 @@ class PackedConv:
         return self.wh, self.wl
 
 
+def range_from_tensor(x: torch.Tensor, packed: PackedConv) -> None:
+    """Set `packed`'s input range record from max|x| ON THE DEVICE (lc_range_from_tensor): the next
+    f16x2 conv of `x` through `packed` splits with the exact scale of this very tensor.  Used by the
+    training graph, where activations / gradients change every step and a backward pass cannot be
+    repeated after a host-side poll."""
+    _req(x, "x")
+    xc = x if x.is_contiguous() else x.contiguous()
+    B = xc.shape[0]
+    n = xc.numel() // B
+    check(lib().lc_range_from_tensor(xc.data_ptr(), n, B, n, packed.range_ptr(x.device), _stream()),
+          "lc_range_from_tensor")
+
+
 def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, out_scale: float = 1.0,
