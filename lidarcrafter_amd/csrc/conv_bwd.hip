@@ -202,7 +202,8 @@ __global__ void bias_grad_fold_kernel(const double* __restrict__ part, float* __
 int wgrad_splits(int B, int Ci, int Co, int H, int W) {
     const int tiles = B * H * ((W + 63) / 64);
     const int ctiles = ((Co + 63) / 64) * ((Ci + 63) / 64);
-    int n = (1024 + ctiles - 1) / ctiles;             // ~4 blocks per CU (2 resident)
+    int n = (512 + ctiles - 1) / ctiles;              // one full wave of blocks (2 resident per CU): equal
+                                                      // work per block, and half the partials to reduce
     if (n > tiles) n = tiles;
     if (n < 1) n = 1;
     return n;
