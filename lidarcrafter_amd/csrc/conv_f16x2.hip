@@ -1680,19 +1680,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int p = blockIdx.x * 256 + threadIdx.x;
     const bool pok = p < HW;
     const long long plane = (long long)B * Co * HW;
+    // all 8 channel planes of a partial in flight together, two partials per round (the first
+    // version walked channel by channel: 8 * ksplit dependent L2 round trips, 14 us per launch)
     float v[8];
+    bool ok[8];
+    const float* pp[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float acc = 0.0f;
-        if (pok && c0 + k < Co) {
-            const float* pp = part + ((long long)b * Co + c0 + k) * HW + p;
-            for (int z = 0; z < ks; ++z) acc += pp[z * plane];
-            if (bias) acc += bias[c0 + k];
-            if (res) acc += res[b * res_bs + (long long)(c0 + k) * HW + p];
-            acc *= out_scale;
-            y[b * y_bs + (long long)(c0 + k) * HW + p] = acc;
-        }
-        v[k] = acc;
+        ok[k] = pok && c0 + k < Co;
+        pp[k] = part + ((long long)b * Co + (ok[k] ? c0 + k : c0)) * HW + (pok ? p : 0);
+        v[k] = 0.0f;
+    }
+    int z = 0;
+    for (; z + 1 < ks; z += 2) {
+        float t0[8], t1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { t0[k] = pp[k][z * plane]; t1[k] = pp[k][(z + 1) * plane]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (v[k] + t0[k]) + t1[k];
+    }
+    if (z < ks) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += pp[k][z * plane];
+    }
+    float bv[8], rv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bv[k] = (bias && ok[k]) ? bias[c0 + k] : 0.0f;
+        rv[k] = (res && ok[k]) ? res[b * res_bs + (long long)(c0 + k) * HW + p] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = ok[k] ? ((v[k] + bv[k]) + rv[k]) * out_scale : 0.0f;
+        if (ok[k]) y[b * y_bs + (long long)(c0 + k) * HW + p] = v[k];
     }
     if (ostats) {                                  // Co % 8 == 0 (checked by the launcher)
         const float piv = __builtin_amdgcn_readfirstlane(v[0]);
