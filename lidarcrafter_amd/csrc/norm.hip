@@ -340,17 +340,26 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     __shared__ double sh[12];
     const int oct = blockIdx.y, b = blockIdx.z;
     const int c0 = oct * 8, cpg = C / G, g = c0 / cpg;
-    float mu, rstd;
+    // per-channel (mean, rstd): one group per octet when cpg >= 8; with 1 / 2 / 4 channels per
+    // group (GroupNorm32 at widths 32 ... 128) the octet spans 8 / cpg groups (partials route only)
+    float mu[8], rstd[8];
     if constexpr (!OS) {
-        const double* pp = part + ((long long)b * G + g) * nch * 2;
-        double s = 0.0, q = 0.0;
-        for (int i = 0; i < nch; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
-        const double n = (double)cpg * (double)HW;
-        const double dm = s / n;
-        double var = q / n - dm * dm;
-        if (var < 0.0) var = 0.0;
-        rstd = (float)(1.0 / sqrt(var + (double)eps));
-        mu = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
+        const int ng = cpg >= 8 ? 1 : 8 / cpg;
+        for (int j = 0; j < ng; ++j) {
+            const int gj = g + j;
+            const double* pp = part + ((long long)b * G + gj) * nch * 2;
+            double s = 0.0, q = 0.0;
+            for (int i = 0; i < nch; ++i) { s += pp[2 * i]; q += pp[2 * i + 1]; }
+            const double n = (double)cpg * (double)HW;
+            const double dm = s / n;
+            double var = q / n - dm * dm;
+            if (var < 0.0) var = 0.0;
+            const float r_ = (float)(1.0 / sqrt(var + (double)eps));
+            const float m_ = (float)((double)x[b * x_bs + (long long)gj * cpg * HW] + dm);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ng == 1 || k / cpg == j) { mu[k] = m_; rstd[k] = r_; }
+        }
     } else {
         const int cg0 = g * cpg;
         const bool seg1 = cg0 >= os.c0;
@@ -386,8 +395,8 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
         const double m = N > 0.0 ? S / N : 0.0;
         double var = N > 0.0 ? Q / N - m * m : 0.0;
         if (var < 0.0) var = 0.0;
-        mu = (float)(P0 + m);
-        rstd = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mu[k] = (float)(P0 + m); rstd[k] = (float)(1.0 / sqrt(var + (double)eps)); }
     }
     float ga[8], be[8], sc[8], sf[8];
 #pragma unroll
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     auto one = [&](const float (&v)[8], half8_t& h8, half8_t& l8) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-            float t0 = (v[k] - mu) * rstd, t1 = (v[k + 1] - mu) * rstd;
+            float t0 = (v[k] - mu[k]) * rstd[k], t1 = (v[k + 1] - mu[k + 1]) * rstd[k + 1];
             t0 = t0 * ga[k] + be[k];         t1 = t1 * ga[k + 1] + be[k + 1];
             t0 = t0 * sc[k] + sf[k];         t1 = t1 * sc[k + 1] + sf[k + 1];
             if (act) { t0 = lc_silu(t0); t1 = lc_silu(t1); }
@@ -566,7 +575,8 @@ extern "C" int lc_groupnorm_apply_split(const float* x, int64_t x_bs, const doub
                                         int H, int W, int G, float eps, int act_silu,
                                         lc_conv_range* range, lc_stream_t s) {
     if (!x || !y_split || !partials || !range || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
-    if (C % 16 || (C / G) % 8) return LC_EUNSUP;
+    const int cpg_ = C / G;
+    if (C % 16 || !(cpg_ % 8 == 0 || cpg_ == 1 || cpg_ == 2 || cpg_ == 4)) return LC_EUNSUP;
     const long long HW = (long long)H * W;
     const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
     OctStats2 os{nullptr, nullptr, 0, 0, 0, 0};

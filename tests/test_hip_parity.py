@@ -881,7 +881,9 @@ def test_temporal_glue_vs_reference_golden(dev, golden):
             dfirst[k] = torch.from_numpy(np.ascontiguousarray(first[k])).to(dev)
         bg, fut_bg, boxes, fut_boxes, Ts, obj_pts, obj_int = T.get_temporal_boxes_3d(dfirst, M=None)
         assert np.array_equal(bg.cpu().numpy(), g[t + "bg"])
-        assert np.array_equal(np.asarray(fut_boxes), g[t + "fut_boxes"]) and np.array_equal(np.asarray(Ts), g[t + "Ts"])
+        # host float64 trigonometry: last-ulp differences between numpy builds / CPUs are allowed
+        assert np.allclose(np.asarray(fut_boxes), g[t + "fut_boxes"], rtol=0, atol=1e-11)
+        assert np.allclose(np.asarray(Ts), g[t + "Ts"], rtol=0, atol=1e-11)
         assert np.abs(fut_bg[0].cpu().numpy() - g[t + "fut_bg_first"]).max() <= 7.7e-6
         assert np.abs(fut_bg[-1].cpu().numpy() - g[t + "fut_bg_last"]).max() <= 7.7e-6
         assert np.array_equal(np.array([p.shape[0] for p in obj_pts]), g[t + "obj_n"])
@@ -892,7 +894,8 @@ def test_temporal_glue_vs_reference_golden(dev, golden):
         assert kept.shape[0] == g[t + "delete_fg"].shape[0]
         assert np.abs(kept.cpu().numpy() - g[t + "delete_fg"]).max() <= 7.7e-6
         m9 = T.get_temporal_boxes_3d(dfirst, M=9)
-        assert np.array_equal(np.asarray(m9[3]), g[t + "M9_fut_boxes"]) and np.array_equal(np.asarray(m9[4]), g[t + "M9_Ts"])
+        assert np.allclose(np.asarray(m9[3]), g[t + "M9_fut_boxes"], rtol=0, atol=1e-11)
+        assert np.allclose(np.asarray(m9[4]), g[t + "M9_Ts"], rtol=0, atol=1e-11)
 
 
 def test_generate_sequence_device_loop(dev):

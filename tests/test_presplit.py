@@ -28,7 +28,10 @@ def decode(sa):
 
 
 @pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 8, 64, 8), (1, 128, 16, 512, 8), (2, 256, 5, 50, 32),
-                                       (1, 32, 3, 7, 2), (3, 512, 4, 128, 32)])
+                                       (1, 32, 3, 7, 2), (3, 512, 4, 128, 32),
+                                       # GroupNorm32 at the narrow widths of the layout denoiser: 4 / 2 / 1
+                                       # channels per group, an octet spans several groups
+                                       (2, 128, 16, 64, 32), (1, 64, 8, 64, 32), (2, 32, 4, 64, 32)])
 @pytest.mark.parametrize("mode", ["plain", "adagn"])
 @pytest.mark.parametrize("route", ["two_pass", "producer_stats"])
 def test_groupnorm_split_matches_fp32_route(dev, B, C, H, W, G, mode, route):
@@ -46,7 +49,7 @@ def test_groupnorm_split_matches_fp32_route(dev, B, C, H, W, G, mode, route):
             pytest.skip("the producer conv needs a pipelined tile shape")
         w = (seeded_randn(C, C, 3, 3, seed=6) / (3 * C ** 0.5)).to(dev)
         x = K.conv2d_ring(x, K.PackedConv(), w, emit_stats=True)
-        assert K._find_stats(x, G) is not None
+        assert (K._find_stats(x, G) is not None) == ((C // G) % 8 == 0)   # narrower groups: statistics pass
     pk = K.PackedConv("consumer")
     ref = K.groupnorm(x.clone(), G, 1e-6, act_silu=True, **kw)
     sa = K.groupnorm(x, G, 1e-6, act_silu=True, split_for=pk, **kw)
