@@ -207,3 +207,42 @@ def test_layout_unet_loss_gradients_and_one_step(dev):
     opt.step()
     with torch.no_grad():
         assert torch.isfinite(ddpm(item))
+
+
+def test_ddp_wraps_the_training_graph(dev):
+    """train_lidm*.py hand `ddpm` to accelerate / DistributedDataParallel.  One rank here (RCCL over a
+    single GPU: world_size 1 exercises process-group init, parameter broadcast, the autograd hooks
+    and the bucketed all-reduce path of DDP around the HIP autograd Functions); gradients must equal
+    the unwrapped module's."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+    from lidargen.models.diffusion import ContinuousTimeGaussianDiffusion
+    from tests.test_hip_parity import _uncond
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m = _uncond(16, (8, 64), dev).train()
+        ddpm = ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).to(dev)
+        x0 = seeded_randn(2, 2, 8, 64, seed=41).clamp(-1, 1).to(dev)
+        torch.manual_seed(7)
+        ddpm(x0).backward()
+        ref = {k: p.grad.clone() for k, p in ddpm.named_parameters() if p.grad is not None}
+        ddpm.zero_grad(set_to_none=True)
+        wrapped = torch.nn.parallel.DistributedDataParallel(ddpm, device_ids=[0], bucket_cap_mb=1)
+        torch.manual_seed(7)                   # same timesteps / noise draw
+        wrapped(x0).backward()
+        got = {k: p.grad for k, p in ddpm.named_parameters() if p.grad is not None}
+        assert got.keys() == ref.keys() and len(ref) > 100
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+    finally:
+        dist.destroy_process_group()
