@@ -287,11 +287,20 @@ __device__ __forceinline__ void publish_amax(lc_conv_range* rg, float am, float 
         atomicMax(reinterpret_cast<unsigned*>(&rg->amax_scaled), __float_as_uint(am));
 }
 
-template <class C>
+template <class C, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
-    constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
-    constexpr int XR = C::XR, XW = C::XW, XU = C::XU, NXU = C::NXU, WU = C::WU, NWU = C::NWU;
+    constexpr int HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
+    constexpr int XR = C::XR, XW = C::XW;
     constexpr int KS = 2 * HALO + 1;
+    // 8-channel blocks per K chunk.  A 1x1 conv has 6 MFMAs per wave and 16 channels: with at most
+    // one round of blocks on the chip (token projections, batch 1) its time is the chunks' global-load
+    // latency and two barriers each, and WIDE stages 64 (or 32) channels per chunk -- four times
+    // fewer barriers, 32 loads per thread in flight (512->512 @8x4x128: 28 -> 21 us, batch 1
+    // 512->256: 24 -> 17 us); with several rounds the narrow chunk's higher occupancy wins
+    // (128->64 @8x32x1024: 43 vs 65 us), r02y / r02z.
+    constexpr int CB = (NTAP == 1 && WIDE) ? ((BN <= 64 && C::TH_ * C::TW_ <= 128) ? 8 : 4) : C::CB;
+    constexpr int XU = CB * XR * XW, NXU = (XU + 255) / 256;
+    constexpr int WU = NTAP * CB * BN, NWU = (WU + 255) / 256;
     __shared__ half8 lds[2 * XU + 2 * WU];
     __shared__ f32x4 ctab[GN_MAX_C];   // fused input GroupNorm rows (mu, A, B, 0) of sample b
     __shared__ float2 gtab[GN_MAX_G];  // (mean, rstd) per group while the rows are derived
@@ -351,9 +360,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
                 const int row = e / BN;                    // tap*CB + cb
                 const int cu = e - row * BN;
                 const int tap = row / CB, cb = row - tap * CB;
-                const long long idx = ((long long)tap * a.Cib + (c0 >> 3) + cb) * a.Cop + co0 + cu;
-                whr[i] = a.wh[idx];
-                wlr[i] = a.wl[idx];
+                const bool in = (c0 >> 3) + cb < a.Cib;         // the last chunk may be partial
+                const long long idx = ((long long)tap * a.Cib + (in ? (c0 >> 3) + cb : 0)) * a.Cop + co0 + cu;
+                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                whr[i] = in ? a.wh[idx] : z;
+                wlr[i] = in ? a.wl[idx] : z;
             }
         }
     };
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
     }
     const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
 
-    const int nchunk = a.Cib / CB;
+    const int nchunk = (a.Cib + CB - 1) / CB;
     if (a.gn) {
         if (a.gs.partials) {
             for (int i = tid; i < a.Cgn; i += 256) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
@@ -410,6 +421,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
             const f32x4* g = a.gn + (long long)b * a.Cgn;
             for (int i = tid; i < a.Cgn; i += 256) ctab[i] = g[i];
         }
+        // zero rows for the channels a partial last chunk stages past the table (x reads 0 there)
+        for (int i = a.Cgn + tid; i < nchunk * 8 * CB && i < GN_MAX_C; i += 256) ctab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
     }
     load_chunk(0);
@@ -421,27 +434,30 @@ __global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int dy = tap / KS, dx = tap - dy * KS;
-            half8 ah[C::TCO_], al[C::TCO_], bh[C::TPX_], bl[C::TPX_];
 #pragma unroll
-            for (int i = 0; i < C::TCO_; ++i) {
-                ah[i] = wh[tap * CB * BN + wbase + i * 32];
-                al[i] = wl[tap * CB * BN + wbase + i * 32];
-            }
+            for (int ks = 0; ks < CB / 2; ++ks) {       // 16 input channels per MFMA K step
+                half8 ah[C::TCO_], al[C::TCO_], bh[C::TPX_], bl[C::TPX_];
 #pragma unroll
-            for (int j = 0; j < C::TPX_; ++j) {
-                bh[j] = xh[xbase[j] + dy * XW + dx];
-                bl[j] = xl[xbase[j] + dy * XW + dx];
-            }
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
+                for (int i = 0; i < C::TCO_; ++i) {
+                    ah[i] = wh[(tap * CB + 2 * ks) * BN + wbase + i * 32];
+                    al[i] = wl[(tap * CB + 2 * ks) * BN + wbase + i * 32];
+                }
 #pragma unroll
                 for (int j = 0; j < C::TPX_; ++j) {
-                    if (LC_F16X2_TERMS & 2)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    if (LC_F16X2_TERMS & 4)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    bh[j] = xh[2 * ks * (XR * XW) + xbase[j] + dy * XW + dx];
+                    bl[j] = xl[2 * ks * (XR * XW) + xbase[j] + dy * XW + dx];
                 }
+#pragma unroll
+                for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TPX_; ++j) {
+                        if (LC_F16X2_TERMS & 2)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        if (LC_F16X2_TERMS & 4)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();
         if (ch + 1 < nchunk) {
@@ -1346,7 +1362,10 @@ int launch_h(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
     dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
-    hipLaunchKernelGGL(conv_f16x2_kernel<C>, grid, dim3(256), 0, st, a);
+    if (C::NTAP == 1 && (long long)grid.x * grid.y <= 512)
+        hipLaunchKernelGGL((conv_f16x2_kernel<C, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_f16x2_kernel<C, false>), grid, dim3(256), 0, st, a);
     return lc_launch_status();
 }
 
