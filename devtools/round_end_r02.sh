@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 T=${1:-r02a}
 O=$PWD/gpurun_out/$T
 mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > $O/smoke.txt
 timeout 500 python bench.py 2>&1 | tail -1 > $O/bench.json
 (cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --repeat 1 --no-verify --no-cpu-baseline --no-roofline > $O/prof.log 2>&1)
