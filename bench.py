@@ -285,7 +285,7 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # N = 1 only (contract)
         steps_per_s = world * args.steps / dt
         line = {
             "metric": "denoising-steps/sec, nuScenes 32\u00d71024 range image, 1/2/4/8 GPU",   # BASELINE.json, verbatim

@@ -132,3 +132,38 @@ def test_f32_kernel_needs_no_range_state(dev):
     y = K.conv2d_ring(x.to(dev), K.PackedConv(), w.to(dev), precision="f32")
     assert K.range_poll(dev) == []
     assert rel_l2(y, ring_conv_f64(x, w)) < 1e-6
+
+
+@pytest.mark.parametrize("mag", [1e-12, 3e-5, 0.7, 1.0, 4097.0, 6.5e4, 1e9])
+def test_range_from_tensor_device_side(dev, mag):
+    """lc_range_from_tensor (training): the record is set on the device to the power of two that
+    puts max|x| into [2^12, 2^13); a conv through it is fp32-class at any magnitude, with no poll."""
+    import math
+
+    from lidarcrafter_amd import ops as K
+
+    x = seeded_randn(2, 32, 4, 64, seed=50) * mag
+    w = seeded_randn(32, 32, 3, 3, seed=51) / 17.0
+    pk = K.PackedConv("train.range")
+    K.range_poll(dev)
+    xd = x.to(dev)
+    K.range_from_tensor(xd, pk)
+    y = K.conv2d_ring(xd, pk, w.to(dev), precision="f16x2")
+    assert rel_l2(y, ring_conv_f64(x, w)) < 2e-6
+    rec = pk._arena.buf.view(-1, 4)[pk._slot].cpu()
+    amax = float(x.abs().max())
+    assert float(rec[0]) == 2.0 ** (13 - math.frexp(amax)[1])      # amax * scale in [2^12, 2^13)
+    assert 4096.0 <= amax * float(rec[0]) < 8192.0
+    assert float(rec[1]) == 1.0 / float(rec[0]) and float(rec[3]) == 0.0
+    assert K.range_poll(dev) == []                                  # nothing for the host to repair
+
+
+def test_range_from_tensor_zero_input(dev):
+    from lidarcrafter_amd import ops as K
+
+    pk = K.PackedConv("train.zero")
+    x = torch.zeros(1, 16, 4, 64, device=dev)
+    K.range_from_tensor(x, pk)
+    y = K.conv2d_ring(x, pk, torch.ones(16, 16, 3, 3, device=dev), precision="f16x2")
+    assert float(y.abs().max()) == 0.0
+    assert float(pk._arena.buf.view(-1, 4)[pk._slot][0]) == 16.0     # the default scale
