@@ -288,7 +288,7 @@ __device__ __forceinline__ void publish_amax(lc_conv_range* rg, float am, float 
 }
 
 template <class C, bool WIDE = false>
-__global__ __launch_bounds__(256, 2) void conv_f16x2_kernel(ConvArgsH a) {
+__global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void conv_f16x2_kernel(ConvArgsH a) {
     constexpr int HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
     constexpr int XR = C::XR, XW = C::XW;
     constexpr int KS = 2 * HALO + 1;
@@ -1362,10 +1362,13 @@ int launch_h(ConvArgsH a, hipStream_t st) {
     a.tiles_h = (a.H + C::TH_ - 1) / C::TH_;
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
     dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
-    if (C::NTAP == 1 && (long long)grid.x * grid.y <= 512)
-        hipLaunchKernelGGL((conv_f16x2_kernel<C, true>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_f16x2_kernel<C, false>), grid, dim3(256), 0, st, a);
+    if constexpr (C::NTAP == 1) {
+        if ((long long)grid.x * grid.y <= 512) {
+            hipLaunchKernelGGL((conv_f16x2_kernel<C, true>), grid, dim3(256), 0, st, a);
+            return lc_launch_status();
+        }
+    }
+    hipLaunchKernelGGL((conv_f16x2_kernel<C, false>), grid, dim3(256), 0, st, a);
     return lc_launch_status();
 }
 

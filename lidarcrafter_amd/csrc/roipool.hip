@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void roi_pool_kernel(int nv, int C, int cap,
     const int total = lst[0];
     if (method == 0) {
         int am = -1;
-        float mx = -1e50f;                              // == -inf in float, like the reference
+        float mx = -__builtin_inff();                   // the reference's -1e50 literal is -inf in float
         for (int k = 1; k <= total; ++k) {
             const float f = feat[(long long)lst[k] * C + c];
             if (f > mx) { mx = f; am = lst[k]; }
