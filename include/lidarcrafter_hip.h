@@ -137,9 +137,9 @@ int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, in
  * of the tensor -- the GroupNorm apply pass in front of almost every conv of the denoisers
  * (efficient_unet.py:101-108, layout_unet_v1.py:171-175) -- can write the split form directly:
  *   y_split: 16-byte units (8 fp16 channels of one pixel), [B][plane = hi, lo][C/8][H][W]
- *            = lc_split_act_units(B, C, H, W) units, the same bytes as fp32 NCHW (needs C % 16 == 0
- *            and groups of whole octets, or -- lc_groupnorm_apply_split only -- of 1 / 2 / 4
- *            channels: LC_EUNSUP otherwise -- use the fp32 forms then),
+ *            = lc_split_act_units(B, C, H, W) units, the same bytes as fp32 NCHW (needs C % 16 == 0;
+ *            lc_groupnorm_apply_os_split also needs groups of whole octets -- LC_EUNSUP otherwise,
+ *            use lc_groupnorm_apply_split or the fp32 forms then),
  * already multiplied by the CONSUMER layer's x_scale (`range`, whose amax_scaled it maintains: the
  * range-safety contract of lc_conv_range moves to the producer).  lc_conv2d_ring_f16x2_ps_fwd then
  * stages its tiles with LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPRs, no VALU, no ds_write in

@@ -340,11 +340,12 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     __shared__ double sh[12];
     const int oct = blockIdx.y, b = blockIdx.z;
     const int c0 = oct * 8, cpg = C / G, g = c0 / cpg;
-    // per-channel (mean, rstd): one group per octet when cpg >= 8; with 1 / 2 / 4 channels per
-    // group (GroupNorm32 at widths 32 ... 128) the octet spans 8 / cpg groups (partials route only)
+    // per-channel (mean, rstd): one group per octet when the groups are whole octets; otherwise
+    // (GroupNorm32 at widths 32 ... 128: 1 / 2 / 4 channels per group; concatenated inputs of 192 /
+    // 384 channels: 6 / 12) the octet spans several groups (partials route only)
     float mu[8], rstd[8];
     if constexpr (!OS) {
-        const int ng = cpg >= 8 ? 1 : 8 / cpg;
+        const int ng = (c0 + 7) / cpg - g + 1;
         for (int j = 0; j < ng; ++j) {
             const int gj = g + j;
             const double* pp = part + ((long long)b * G + gj) * nch * 2;
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
             const float m_ = (float)((double)x[b * x_bs + (long long)gj * cpg * HW] + dm);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (ng == 1 || k / cpg == j) { mu[k] = m_; rstd[k] = r_; }
+                if ((c0 + k) / cpg == gj) { mu[k] = m_; rstd[k] = r_; }
         }
     } else {
         const int cg0 = g * cpg;
@@ -575,8 +576,7 @@ extern "C" int lc_groupnorm_apply_split(const float* x, int64_t x_bs, const doub
                                         int H, int W, int G, float eps, int act_silu,
                                         lc_conv_range* range, lc_stream_t s) {
     if (!x || !y_split || !partials || !range || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
-    const int cpg_ = C / G;
-    if (C % 16 || !(cpg_ % 8 == 0 || cpg_ == 1 || cpg_ == 2 || cpg_ == 4)) return LC_EUNSUP;
+    if (C % 16) return LC_EUNSUP;
     const long long HW = (long long)H * W;
     const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
     OctStats2 os{nullptr, nullptr, 0, 0, 0, 0};

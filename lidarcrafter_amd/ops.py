@@ -498,8 +498,7 @@ class SplitAct:
 
 
 def can_presplit(C: int, G: int) -> bool:
-    return PRESPLIT and CONV_PRECISION == "f16x2" and C % 16 == 0 and G > 0 and C % G == 0 and \
-        ((C // G) % 8 == 0 or (C // G) in (1, 2, 4))
+    return PRESPLIT and CONV_PRECISION == "f16x2" and C % 16 == 0 and G > 0 and C % G == 0
 
 
 class PackedConv:

@@ -31,7 +31,9 @@ def decode(sa):
                                        (1, 32, 3, 7, 2), (3, 512, 4, 128, 32),
                                        # GroupNorm32 at the narrow widths of the layout denoiser: 4 / 2 / 1
                                        # channels per group, an octet spans several groups
-                                       (2, 128, 16, 64, 32), (1, 64, 8, 64, 32), (2, 32, 4, 64, 32)])
+                                       (2, 128, 16, 64, 32), (1, 64, 8, 64, 32), (2, 32, 4, 64, 32),
+                                       # concatenated inputs: 6 / 12 / 3 channels per group
+                                       (2, 192, 8, 64, 32), (1, 384, 4, 128, 32), (1, 96, 4, 64, 32)])
 @pytest.mark.parametrize("mode", ["plain", "adagn"])
 @pytest.mark.parametrize("route", ["two_pass", "producer_stats"])
 def test_groupnorm_split_matches_fp32_route(dev, B, C, H, W, G, mode, route):
