@@ -51,7 +51,21 @@ def training_active(module: torch.nn.Module, *tensors) -> bool:
 
 
 def _c4(t):
-    return t if t.is_contiguous() else t.contiguous()
+    """A [B,C,H,W] tensor the kernels can take as it is: inner [C,H,W] block contiguous, ANY batch
+    stride (the gradient of a channel concatenation arrives as a slice of the concatenated
+    gradient -- copying it would cost a pass over the tensor per conv); anything else is copied."""
+    if t.dim() == 4:
+        B, C, H, W = t.shape
+        st = t.stride()
+        if (W == 1 or st[3] == 1) and (H == 1 or st[2] == W) and (C == 1 or st[1] == H * W) and \
+                (B == 1 or st[0] >= C * H * W):
+            return t
+    return t.contiguous()
+
+
+def _bs(t):
+    """Batch stride in elements of a tensor accepted by _c4."""
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * t.shape[3]
 
 
 class ConvRing(torch.autograd.Function):
@@ -85,7 +99,7 @@ class ConvRing(torch.autograd.Function):
             n = int(lib().lc_conv2d_ring_wgrad_scratch_elems(B, Ci, Co, H, W, ks))
             scratch = torch.empty(n, device=x.device, dtype=torch.float32)
             with torch.cuda.device(x.device):
-                check(lib().lc_conv2d_ring_wgrad(x.data_ptr(), Ci * H * W, dy.data_ptr(), Co * H * W,
+                check(lib().lc_conv2d_ring_wgrad(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy),
                                                  scratch.data_ptr(), dw.data_ptr(),
                                                  None if db is None else db.data_ptr(), B, Ci, Co, H,
                                                  W, ks, 0, torch.cuda.current_stream().cuda_stream),
@@ -116,15 +130,15 @@ class GroupNormAct(torch.autograd.Function):
         n = int(lib().lc_groupnorm_partials_elems(B, C, H, W, G))
         part = torch.empty(n, device=dev, dtype=torch.float64)
         mr = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, device=dev, dtype=torch.float32)
         p = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
-            check(lib().lc_groupnorm_stats(x.data_ptr(), C * H * W, part.data_ptr(), B, C, H, W, G, st),
+            check(lib().lc_groupnorm_stats(x.data_ptr(), _bs(x), part.data_ptr(), B, C, H, W, G, st),
                   "lc_groupnorm_stats")
-            check(lib().lc_groupnorm_meanrstd(x.data_ptr(), C * H * W, part.data_ptr(), mr.data_ptr(), B,
+            check(lib().lc_groupnorm_meanrstd(x.data_ptr(), _bs(x), part.data_ptr(), mr.data_ptr(), B,
                                               C, H, W, G, float(eps), st), "lc_groupnorm_meanrstd")
-            check(lib().lc_groupnorm_apply(x.data_ptr(), C * H * W, part.data_ptr(), p(gamma), p(beta),
+            check(lib().lc_groupnorm_apply(x.data_ptr(), _bs(x), part.data_ptr(), p(gamma), p(beta),
                                            p(sc), p(sf), C, y.data_ptr(), C * H * W, B, C, H, W, G,
                                            float(eps), int(act), st), "lc_groupnorm_apply")
         ctx.save_for_backward(x, mr, gamma, beta, sc, sf)
@@ -137,10 +151,10 @@ class GroupNormAct(torch.autograd.Function):
         dy = _c4(dy)
         B, C, H, W = x.shape
         rows = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         p = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(x.device):
-            check(lib().lc_groupnorm_bwd(x.data_ptr(), C * H * W, dy.data_ptr(), C * H * W, mr.data_ptr(),
+            check(lib().lc_groupnorm_bwd(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), mr.data_ptr(),
                                          p(gamma), p(beta), p(sc), p(sf), C, rows.data_ptr(),
                                          dx.data_ptr(), C * H * W, B, C, H, W, ctx.G, int(ctx.act),
                                          torch.cuda.current_stream().cuda_stream), "lc_groupnorm_bwd")

@@ -579,10 +579,14 @@ def range_from_tensor(x: torch.Tensor, packed: PackedConv) -> None:
     training graph, where activations / gradients change every step and a backward pass cannot be
     repeated after a host-side poll."""
     _req(x, "x")
-    xc = x if x.is_contiguous() else x.contiguous()
-    B = xc.shape[0]
-    n = xc.numel() // B
-    check(lib().lc_range_from_tensor(xc.data_ptr(), n, B, n, packed.range_ptr(x.device), _stream()),
+    B = x.shape[0]
+    n = x.numel() // B
+    if x.dim() == 4:
+        x_bs = _bs4(x, "x")                       # inner block contiguous, any batch stride
+    else:
+        x = x if x.is_contiguous() else x.contiguous()
+        x_bs = n
+    check(lib().lc_range_from_tensor(x.data_ptr(), x_bs, B, n, packed.range_ptr(x.device), _stream()),
           "lc_range_from_tensor")
 
 
