@@ -7,7 +7,9 @@ of lidarcrafter_amd through the C ABI instead of ATen:
   Resample (ref ops.py:52-146)                -> lc_resample2x_fwd  (closed-form FIR, one pass)
   AdaGN    (ref ops.py:176-200)               -> lc_groupnorm_stats/apply (+scale/shift, +SiLU)
   SinusoidalPositionalEmbedding (ref :14-29)  -> lc_sinusoid_fwd
-Inference only: these modules have no autograd graph (training = SURVEY.md §8f-4, later round).
+Their `forward` is the inference path (no autograd graph); training takes the composition of the same
+layers in lidarcrafter_amd/autograd.py, which the denoisers' `forward` selects when
+grad mode is on.
 """
 from __future__ import annotations
 
