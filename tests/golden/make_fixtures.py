@@ -448,6 +448,55 @@ def sec_caller_names():
     print("caller_names.json", {k: len(v) for k, v in res.items()})
 
 
+def _grad_digest(named_params):
+    """Per parameter: L2 norm of the gradient and its first 8 entries (flattened) -- enough to pin
+    every parameter's gradient without storing megabytes."""
+    names, norms, heads = [], [], []
+    for k, p_ in named_params:
+        if p_.grad is None:
+            continue
+        g = p_.grad.detach().double().flatten()
+        names.append(k)
+        norms.append(float(g.norm()))
+        h = torch.zeros(8, dtype=torch.float64)
+        h[: min(8, g.numel())] = g[:8]
+        heads.append(h)
+    return np.array(names), np.array(norms), torch.stack(heads).numpy()
+
+
+def sec_train():
+    """Training step of the REFERENCE modules under torch autograd (tools/train/train_lidm.py:214-265,
+    train_lidm_cond.py:259-322): loss of one denoising step at fixed timesteps / noise and the
+    gradient of every parameter -- reduced EfficientUNet, reduced LayoutUnetV1 + layout encoder
+    (eval mode: dropout off)."""
+    eu = R.ref("models.unets.efficient_unet")
+    out = {}
+    m = _build_uncond(eu, 16, (8, 64))
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    x_t = seeded_randn(2, 2, 8, 64, seed=61)
+    noise = seeded_randn(2, 2, 8, 64, seed=62)
+    lam = torch.tensor([-2.5, 1.0])
+    loss = ((m(x_t, lam) - noise) ** 2).mean()
+    loss.backward()
+    out["u_loss"] = loss.detach()
+    out["u_names"], out["u_norms"], out["u_heads"] = _grad_digest(m.named_parameters())
+    mc, enc = _build_cond((8, 64), 8, 32)
+    for p_ in list(mc.parameters()) + list(enc.parameters()):
+        p_.requires_grad_(True)
+    batch = synth_layout_batch(2, 8, 64, seed=51)
+    x_t = seeded_randn(2, 2, 8, 64, seed=63)
+    noise = seeded_randn(2, 2, 8, 64, seed=64)
+    lam = torch.tensor([-1.5, 2.0])
+    cond = enc(batch)
+    loss = ((mc(x_t, {"time_condition": lam, "other_condition": cond}) - noise) ** 2).mean()
+    loss.backward()
+    out["c_loss"] = loss.detach()
+    out["c_names"], out["c_norms"], out["c_heads"] = _grad_digest(
+        [("unet." + k, v) for k, v in mc.named_parameters()] + [("enc." + k, v) for k, v in enc.named_parameters()])
+    save("train", **out)
+
+
 def sec_object():
     """Foreground-object branch: ObjectGenEncoder (encoders/object_gen_encoder.py:7-88) with
     synthetic class text features, PointUNet (point_unet.py:14-71) forward, and 4-step DDPM / DDIM

@@ -246,3 +246,50 @@ def test_ddp_wraps_the_training_graph(dev):
             assert torch.equal(got[k], ref[k]), k
     finally:
         dist.destroy_process_group()
+
+
+def _digest_check(named_params, names, norms, heads, tol):
+    import numpy as np
+
+    grads = {k: p.grad for k, p in named_params if p.grad is not None}
+    top = float(norms.max())
+    worst = 0.0
+    for k, n_, h in zip(names, norms, heads):
+        gr = grads[str(k)].detach().double().cpu().flatten()
+        err = abs(float(gr.norm()) - n_)
+        assert err <= tol * n_ + 1e-6 * top, (k, float(gr.norm()), n_)
+        m = min(8, gr.numel())
+        assert np.allclose(gr[:m].numpy(), h[:m], rtol=0, atol=tol * max(n_, 1e-3 * top)), k
+        if n_ > 1e-4 * top:
+            worst = max(worst, err / n_)
+    return worst
+
+
+def test_training_gradients_vs_reference_golden(dev, golden):
+    """The HIP training graph against gradients of the REFERENCE modules under torch autograd
+    (tests/golden/train.npz, make_fixtures.py section `train`): loss and every parameter's gradient
+    (norm + leading entries) of the reduced EfficientUNet and of the reduced LayoutUnetV1 + layout
+    encoder."""
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from tests.test_hip_parity import _uncond
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    g = golden("train")
+    m = _uncond(16, (8, 64), dev)
+    loss = ((m(seeded_randn(2, 2, 8, 64, seed=61).to(dev), torch.tensor([-2.5, 1.0], device=dev)) -
+             seeded_randn(2, 2, 8, 64, seed=62).to(dev)) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["u_loss"])) < 1e-5 * float(g["u_loss"])
+    w1 = _digest_check(m.named_parameters(), g["u_names"], g["u_norms"], g["u_heads"], 3e-4)
+    mc, enc = build_cond_pair((8, 64), 8, 32)
+    mc, enc = mc.to(dev), enc.to(dev)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(2, 8, 64, seed=51).items()}
+    cond = enc(batch)
+    loss = ((mc(seeded_randn(2, 2, 8, 64, seed=63).to(dev),
+                {"time_condition": torch.tensor([-1.5, 2.0], device=dev), "other_condition": cond}) -
+             seeded_randn(2, 2, 8, 64, seed=64).to(dev)) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["c_loss"])) < 1e-5 * float(g["c_loss"])
+    named = [("unet." + k, v) for k, v in mc.named_parameters()] + [("enc." + k, v) for k, v in enc.named_parameters()]
+    w2 = _digest_check(named, g["c_names"], g["c_norms"], g["c_heads"], 3e-4)
+    print(f"worst gradient-norm deviation vs the reference: uncond {w1:.2e}, layout-conditioned {w2:.2e}")
