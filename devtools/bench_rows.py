@@ -48,7 +48,8 @@ def uncond(dev, B, res, steps, key):
     assert torch.isfinite(st["x"]).all()
     return {"batch": B, "resolution": list(res), "ms_per_step": round(dt * 1e3, 3),
             "steps_per_s": round(1 / dt, 2), "sample_steps_per_s": round(B / dt, 1),
-            "algorithmic_tflops": round(B * GFLOP[key] / dt / 1e3, 1)}
+            "algorithmic_tflops": round(B * GFLOP[key] / dt / 1e3, 1),
+            "frac_of_f16_mfma_peak": round(B * GFLOP[key] / dt / 1e3 / 2500.0, 4)}
 
 
 def cond(dev, B, steps):
@@ -75,6 +76,7 @@ def cond(dev, B, steps):
     return {"batch": B, "resolution": [32, 1024], "ms_per_step": round(dt * 1e3, 3),
             "steps_per_s": round(1 / dt, 2), "sample_steps_per_s": round(B / dt, 1),
             "algorithmic_tflops": round(B * GFLOP["cond32"] / dt / 1e3, 1),
+            "frac_of_f16_mfma_peak": round(B * GFLOP["cond32"] / dt / 1e3 / 2500.0, 4),
             "layout_encoder_ms_once_per_batch": round(t_enc * 1e3, 2)}
 
 
