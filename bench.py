@@ -282,6 +282,12 @@ def main():
                 "time_share_per_family_ms_per_step": {
                     k: round(v[1] / n_prof * 1e3, 3) for k, v in sorted(fam.items())}}
     if dist_on:
+        # RCCL prints a version banner through C stdio; piped, it would be flushed at process exit, i.e.
+        # AFTER rank 0's JSON line.  Every rank flushes its C streams before the last barrier, so the
+        # JSON line is the last thing on stdout.
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
         dist.barrier()
 
     if rank == 0:
