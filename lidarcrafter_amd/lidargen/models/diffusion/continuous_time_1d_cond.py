@@ -10,6 +10,8 @@ scalars broadcast over [N, C] exactly as the reference's `squeeze_(-1)` forms do
 is simply viewed as a one-row image [B, 1, N, C] for the elementwise update."""
 from __future__ import annotations
 
+import contextlib
+
 from typing import Literal
 
 import torch
@@ -90,7 +92,10 @@ class CondContinuousLayoutGaussianDiffusion1D(CondContinuousTimeGaussianDiffusio
         x_0 = input_dict["x_0"]
         loss_mask = torch.ones_like(x_0) if loss_mask is None else loss_mask
         x_t, noise = self.q_step_from_x_0(x_0, steps)
-        condition = self.get_network_condition(steps, input_dict)
-        with torch.no_grad():
+        from lidarcrafter_amd import autograd as AG
+
+        train = AG.training_active(self.model) or AG.training_active(self.condition_model)
+        with (contextlib.nullcontext() if train else torch.no_grad()):
+            condition = self.get_network_condition(steps, input_dict)
             prediction = self.model(x_t, condition)
         return self._masked_loss(prediction, self.get_target(x_0, steps, noise), loss_mask, steps)

@@ -11,8 +11,10 @@ from __future__ import annotations
 import pickle
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
+from lidarcrafter_amd import autograd as AG
 from lidarcrafter_amd import ops as K
 
 from .embedder import get_embedder
@@ -60,9 +62,13 @@ class ObjectGenEncoder(nn.Module):
         lead = pos_emb.shape[:-1]
         p = pos_emb.reshape(-1, pos_emb.shape[-1]).float().contiguous()
         c = cls_emb.reshape(-1, cls_emb.shape[-1]).float()
+        sl = self.second_linear
+        if AG.training_active(self, p, c):           # training (tools/train/train_object.py): torch ops
+            h = F.silu(F.linear(p, self.bbox_proj.weight, self.bbox_proj.bias))
+            h = sl(torch.cat([h, c], dim=-1))
+            return h.reshape(*lead, h.shape[-1])
         h = K.linear(p, self.bbox_proj.weight, self.bbox_proj.bias, act_out=True)
         h = torch.cat([h, c], dim=-1).contiguous()
-        sl = self.second_linear
         h = K.linear(h, sl[0].weight, sl[0].bias, act_out=True)
         h = K.linear(h, sl[2].weight, sl[2].bias, act_out=True)
         h = K.linear(h, sl[4].weight, sl[4].bias)

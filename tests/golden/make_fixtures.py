@@ -494,6 +494,25 @@ def sec_train():
     out["c_loss"] = loss.detach()
     out["c_names"], out["c_norms"], out["c_heads"] = _grad_digest(
         [("unet." + k, v) for k, v in mc.named_parameters()] + [("enc." + k, v) for k, v in enc.named_parameters()])
+    # foreground-object branch (tools/train/train_object.py): PointUNet + ObjectGenEncoder
+    from lidarcrafter_amd.testing import synth_object_batch, synth_text_features
+
+    pu = R.ref("models.unets.point_unet")
+    oe = R.ref("models.unets.encoders.object_gen_encoder")
+    mo = seeded_fill(pu.PointUNet(point_dim=4, cond_dims=768), salt=300).eval()
+    eo = seeded_fill(oe.ObjectGenEncoder(num_class=8), salt=301).eval()
+    eo.obj_text_feat = synth_text_features()
+    eo.prepare_called = True
+    for p_ in list(mo.parameters()) + list(eo.parameters()):
+        p_.requires_grad_(True)
+    ob = synth_object_batch(3, seed=95)
+    x_t = seeded_randn(3, 1024, 4, seed=65)
+    noise = seeded_randn(3, 1024, 4, seed=66)
+    loss = ((mo(x_t, {"time_condition": torch.tensor([-6.0, 0.5, 9.0]), "other_condition": eo(ob)}) - noise) ** 2).mean()
+    loss.backward()
+    out["o_loss"] = loss.detach()
+    out["o_names"], out["o_norms"], out["o_heads"] = _grad_digest(
+        [("unet." + k, v) for k, v in mo.named_parameters()] + [("enc." + k, v) for k, v in eo.named_parameters()])
     save("train", **out)
 
 

@@ -293,3 +293,37 @@ def test_training_gradients_vs_reference_golden(dev, golden):
     named = [("unet." + k, v) for k, v in mc.named_parameters()] + [("enc." + k, v) for k, v in enc.named_parameters()]
     w2 = _digest_check(named, g["c_names"], g["c_norms"], g["c_heads"], 3e-4)
     print(f"worst gradient-norm deviation vs the reference: uncond {w1:.2e}, layout-conditioned {w2:.2e}")
+
+
+def test_object_branch_training_gradients_vs_reference_golden(dev, golden):
+    """tools/train/train_object.py: PointUNet + ObjectGenEncoder under grad mode (differentiable torch
+    ops on the device) against gradients of the reference modules (tests/golden/train.npz), then
+    `ddpm(batch)` + AdamW as the script calls it."""
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+    from lidarcrafter_amd.testing import synth_object_batch, synth_text_features
+
+    g = golden("train")
+    ddpm, model = inference.load_model_object_duffusion_training(C["nuscenes-object"]())
+    seeded_fill(model, salt=300), seeded_fill(ddpm.condition_model, salt=301)
+    ddpm = ddpm.to(dev)
+    enc = ddpm.condition_model
+    enc.set_text_features(synth_text_features(), dev)
+    batch = {k: v.to(dev) for k, v in synth_object_batch(3, seed=95).items()}
+    pred = ddpm.model(seeded_randn(3, 1024, 4, seed=65).to(dev),
+                      {"time_condition": torch.tensor([-6.0, 0.5, 9.0], device=dev), "other_condition": enc(batch)})
+    assert pred.requires_grad
+    loss = ((pred - seeded_randn(3, 1024, 4, seed=66).to(dev)) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["o_loss"])) < 1e-5 * float(g["o_loss"])
+    named = [("unet." + k, v) for k, v in ddpm.model.named_parameters()] + \
+            [("enc." + k, v) for k, v in enc.named_parameters()]
+    w = _digest_check(named, g["o_names"], g["o_norms"], g["o_heads"], 3e-4)
+    print(f"object branch: worst gradient-norm deviation vs the reference {w:.2e}")
+    opt = torch.optim.AdamW(ddpm.parameters(), lr=1e-4)
+    opt.zero_grad()
+    item = dict(batch)
+    item["x_0"] = seeded_randn(3, 1024, 4, seed=67).clamp(-1, 1).to(dev)
+    ddpm(item).backward()
+    assert all(torch.isfinite(p.grad).all() for p in ddpm.parameters() if p.grad is not None)
+    opt.step()
