@@ -30,6 +30,7 @@ def dev():
     (2, 128, 256, 8, 256, 3), (2, 512, 512, 4, 128, 3), (1, 64, 2, 32, 256, 3),
     (2, 42, 64, 8, 64, 3), (1, 512, 256, 4, 128, 1), (2, 48, 144, 1, 8, 3), (3, 16, 32, 2, 16, 3),
     (2, 64, 96, 1, 2048, 1), (1, 32, 64, 1, 192, 1),
+    (2, 96, 64, 4, 64, 1), (1, 192, 64, 8, 64, 1),      # 1x1 with a partial last 64-channel chunk
 ])
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 223, 423, 425, 412, 212, 28, 228])
 @pytest.mark.parametrize("prec", ["f32", "f16x2"])
