@@ -32,7 +32,8 @@ extern "C" {
 
 typedef void* lc_stream_t;
 
-/* Library / device probe.  Returns the ABI version (this header = 1). */
+/* Library / device probe.  Returns the ABI version (this header = 2: round 3 -- field-of-view
+ * arguments are doubles, lc_layout_condition takes float32 or float64 boxes, float64 point sets). */
 int lc_abi_version(void);
 /* Writes gcnArchName of the current device into buf (NUL terminated). */
 int lc_device_arch(char* buf, int buflen);
@@ -361,9 +362,18 @@ int lc_sparse_quantize(const float* coords, int N, int D, float vx, float vy, fl
  * (oracle/lidar.py "native_cr" -- the mode the committed reference fixtures are reproduced in);
  * 0: all-float32, the reference under its pinned numpy 1.23.5 (oracle "f32").
  * ------------------------------------------------------------------------------------------- */
-int lc_project_points(const float* points, int N, int H, int W, float fov_up_deg,
-                      float fov_down_deg, float min_depth, float max_depth, uint64_t* zbuf,
+int lc_project_points(const float* points, int N, int H, int W, double fov_up_deg,
+                      double fov_down_deg, float min_depth, float max_depth, uint64_t* zbuf,
                       float* image, int32_t* winner, int32_t* cells, int elev_f64, lc_stream_t s);
+/* The same projection of FLOAT64 points [N,4] -- what the temporal glue hands over
+ * (tools/vis_tools/utils/pipe_related.py:245-258: the float64 product `Ts @ homo` and the float64
+ * concatenation [background | re-posed objects]): every line of common.py:41-84 runs in float64
+ * and the image is rounded to float32 once (:87-91).  winner int32[H*W] is REQUIRED (pass 2 of the
+ * z-buffer: lowest index among the points at the cell's minimum depth).  Pinned on the reference's
+ * own CustomDataset item / refine_next_frame_points (tests/golden/pipe_next.npz). */
+int lc_project_points_f64(const double* points, int N, int H, int W, double fov_up_deg,
+                          double fov_down_deg, double min_depth, double max_depth, uint64_t* zbuf,
+                          int32_t* winner, float* image, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Points in rotated boxes: lidargen/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:128-168
@@ -403,10 +413,13 @@ int lc_condition_preprocess(const float* condition_mask, int64_t cm_bs, float* o
  *    loss_weight_map [B,H,W] (may be NULL).  scratch: lc_layout_scratch_bytes(B,T) bytes.
  * ------------------------------------------------------------------------------------------- */
 int64_t lc_layout_scratch_bytes(int B, int T);
-int lc_layout_condition(const float* boxes, int box_stride, const int32_t* n_valid, int B, int T,
-                        int H, int W, float fov_up_deg, float fov_down_deg, void* scratch,
-                        float* corners_2d, float* condition_mask, float* loss_weight_map,
-                        lc_stream_t s);
+/* boxes_f64 = 0: float32 boxes (yaw cos/sin and centre depth in float32, like numpy on float32
+ * input); 1: float64 boxes -- what NuscDataset.pre_process hands over (nuscenes_dataset.py:384-397)
+ * -- everything in float64, the centre depth rounded to float32 when painted. */
+int lc_layout_condition(const void* boxes, int boxes_f64, int box_stride, const int32_t* n_valid,
+                        int B, int T, int H, int W, double fov_up_deg, double fov_down_deg,
+                        void* scratch, float* corners_2d, float* condition_mask,
+                        float* loss_weight_map, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * RoI-aware voxel pooling of point features: lidargen/ops/roiaware_pool3d/
@@ -446,6 +459,12 @@ int lc_roiaware_pool3d_bwd(const int32_t* pts_idx_of_voxels, const int32_t* argm
  *    kept row; scratch = lc_compact_scratch_elems(N) int32.  Three launches, no host sync.
  * ------------------------------------------------------------------------------------------- */
 int lc_transform_points(const float* pts, int N, const double* T16_host, float* out, lc_stream_t s);
+/* float64 rows out [N,4] (32-byte aligned), NOT rounded: the reference keeps `(Ts @ homo_pts.T).T`
+ * in float64 and projects it in float64 (pipe_related.py:245-257).  rot_f32 = 1: out.xyz =
+ * (double)(float)(R p) + t, i.e. `rotate_points_along_z(p, yaw)` (float32 matmul,
+ * lidargen/dataset/utils.py:37-59) `+ np.array([x, y, z])` (float64), pipe_related.py:263-266. */
+int lc_transform_points_f64(const float* pts, int N, const double* T16_host, int rot_f32,
+                            double* out, lc_stream_t s);
 int lc_image_to_points(const float* xyz, int64_t plane_stride, const float* refl, const float* cond,
                        int H, int W, float refl_scale, float min_norm, float ego_radius, float* pts,
                        int32_t* keep, lc_stream_t s);

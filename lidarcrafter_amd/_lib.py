@@ -7,7 +7,7 @@ import os
 
 from .build import LIB
 
-i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+i32, i64, f32, f64, vp = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
 
 class CmOperand(C.Structure):
@@ -87,17 +87,19 @@ SIGNATURES = {
     "lc_gate_bias_act": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),
     "lc_add_scale": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, f32, vp]),
-    "lc_project_points": (i32, [vp, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp]),
+    "lc_project_points": (i32, [vp, i32, i32, i32, f64, f64, f32, f32, vp, vp, vp, vp, i32, vp]),
+    "lc_project_points_f64": (i32, [vp, i32, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp]),
     "lc_range_postprocess": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "lc_condition_preprocess": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, f32, vp]),
     "lc_layout_scratch_bytes": (i64, [i32, i32]),
-    "lc_layout_condition": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
+    "lc_layout_condition": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, f64, f64, vp, vp, vp, vp, vp]),
     "lc_roiaware_pool3d_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp,
                                      vp, vp]),
     "lc_roiaware_pool3d_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lc_points_in_boxes_mask": (i32, [vp, i32, vp, i32, f32, vp, vp]),
     "lc_points_in_boxes_mask4": (i32, [vp, i32, vp, i32, f32, vp, vp, vp]),
     "lc_transform_points": (i32, [vp, i32, C.POINTER(C.c_double), vp, vp]),
+    "lc_transform_points_f64": (i32, [vp, i32, C.POINTER(C.c_double), i32, vp, vp]),
     "lc_image_to_points": (i32, [vp, i64, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp]),
     "lc_bev_occupancy_accumulate": (i32, [vp, i32, i32, f32, f32, f32, f32, f32, i32, i32, i32, i32,
                                           i32, vp, vp, vp]),
@@ -131,7 +133,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.lc_abi_version() != 1:
+        if handle.lc_abi_version() != 2:
             raise HipLibraryMissing("ABI version mismatch, rebuild the library")
         _lib = handle
     return _lib

@@ -80,6 +80,72 @@ __global__ __launch_bounds__(256) void project_gather_kernel(const float* __rest
     if (winner) winner[c] = win;
 }
 
+// ---- float64 point sets (round 3) -----------------------------------------------------------------
+// The temporal glue hands `load_points_as_images` FLOAT64 points (pipe_related.py:245-258: the
+// float64 product `Ts @ homo`, and the float64 concatenation [background | re-posed objects]); every
+// line of common.py:41-84 then runs in float64 and the image is rounded to float32 once (:87-91).
+// A 64-bit depth leaves no room for the index in one atomic key: pass 1 = atomicMin of the depth
+// bits per cell, pass 2 = atomicMin of the index among the points AT that depth (lowest index wins,
+// the same tie rule as the float32 path), pass 3 = gather.
+__device__ __forceinline__ void cell_of64(double x, double y, double z, int H, int W, double h_up,
+                                          double h_down, double& depth, int& gh, int& gw) {
+    depth = sqrt((x * x + y * y) + z * z);
+    const double elev = asin(z / (depth + 1e-6)) + fabs(h_down);
+    double fh = 1.0 - elev / (h_up - h_down);
+    fh = floor(fh * (double)H);
+    gh = (int)fmin(fmax(fh, 0.0), (double)(H - 1));
+    double fw = (-atan2(y, x) / 3.141592653589793 + 1.0) / 2.0;
+    fw = fw - floor(fw);               // np.mod(v, 1)
+    fw = floor(fw * (double)W);
+    gw = (int)fmin(fmax(fw, 0.0), (double)(W - 1));
+}
+
+__global__ void zbuf64_clear_kernel(unsigned long long* zb, int* win, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { zb[i] = ~0ull; win[i] = 0x7fffffff; }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void project64_scatter_kernel(const double* __restrict__ pts, int N,
+                                                               int H, int W, double h_up,
+                                                               double h_down,
+                                                               unsigned long long* __restrict__ zb,
+                                                               int* __restrict__ win) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double x = pts[4ll * i], y = pts[4ll * i + 1], z = pts[4ll * i + 2];
+    double depth; int gh, gw;
+    cell_of64(x, y, z, H, W, h_up, h_down, depth, gh, gw);
+    if (depth != depth) return;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(depth);  // depth >= 0
+    const long long c = (long long)gh * W + gw;
+    if (PASS == 0) atomicMin(zb + c, key);
+    else if (zb[c] == key) atomicMin(win + c, i);
+}
+
+__global__ __launch_bounds__(256) void project64_gather_kernel(const double* __restrict__ pts, int HW,
+                                                              const unsigned long long* __restrict__ zb,
+                                                              double min_d, double max_d,
+                                                              float* __restrict__ img,
+                                                              int* __restrict__ winner) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= HW) return;
+    const unsigned long long key = zb[c];
+    float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int win = -1;
+    if (key != ~0ull) {
+        win = winner[c];
+        const double depth = __longlong_as_double((long long)key);
+        o[0] = (float)pts[4ll * win]; o[1] = (float)pts[4ll * win + 1];
+        o[2] = (float)pts[4ll * win + 2]; o[3] = (float)pts[4ll * win + 3];
+        o[4] = (float)depth;
+        o[5] = (depth >= min_d && depth <= max_d) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) img[6ll * c + k] = o[k];
+    winner[c] = win;
+}
+
 // roiaware_pool3d.cpp:121-140 / roiaware_pool3d_kernel.cu:16-36: float rotation, double compares.
 __device__ __forceinline__ int pt_in_box(float x, float y, float z, const float* bx, float margin) {
     const float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5], rz = bx[6];
@@ -144,16 +210,16 @@ __global__ __launch_bounds__(256) void pib_index_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int lc_project_points(const float* points, int N, int H, int W, float fov_up_deg,
-                                 float fov_down_deg, float min_depth, float max_depth,
+extern "C" int lc_project_points(const float* points, int N, int H, int W, double fov_up_deg,
+                                 double fov_down_deg, float min_depth, float max_depth,
                                  uint64_t* zbuf, float* image, int32_t* winner, int32_t* cells,
                                  int elev_f64, lc_stream_t s) {
     if ((!points && N > 0) || !zbuf || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
     if (reinterpret_cast<uintptr_t>(points) & 15) return LC_EINVAL;
     const int HW = H * W;
     // np.deg2rad in float64 (rounded to float32 inside the kernel for the all-float32 mode)
-    const double h_up = (double)fov_up_deg * 0.017453292519943295;
-    const double h_down = (double)fov_down_deg * 0.017453292519943295;
+    const double h_up = fov_up_deg * 0.017453292519943295;
+    const double h_down = fov_down_deg * 0.017453292519943295;
     auto zb = reinterpret_cast<unsigned long long*>(zbuf);
     hipLaunchKernelGGL(zbuf_clear_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), zb, HW);
     if (N > 0) {
@@ -165,6 +231,26 @@ extern "C" int lc_project_points(const float* points, int N, int H, int W, float
                                lc_s(s), points, N, H, W, h_up, h_down, zb, cells);
     }
     hipLaunchKernelGGL(project_gather_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
+                       HW, zb, min_depth, max_depth, image, winner);
+    return lc_launch_status();
+}
+
+extern "C" int lc_project_points_f64(const double* points, int N, int H, int W, double fov_up_deg,
+                                     double fov_down_deg, double min_depth, double max_depth,
+                                     uint64_t* zbuf, int32_t* winner, float* image, lc_stream_t s) {
+    if ((!points && N > 0) || !zbuf || !winner || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
+    const int HW = H * W;
+    const double h_up = fov_up_deg * 0.017453292519943295;
+    const double h_down = fov_down_deg * 0.017453292519943295;
+    auto zb = reinterpret_cast<unsigned long long*>(zbuf);
+    hipLaunchKernelGGL(zbuf64_clear_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), zb, winner, HW);
+    if (N > 0) {
+        hipLaunchKernelGGL(project64_scatter_kernel<0>, dim3((N + 255) / 256), dim3(256), 0, lc_s(s),
+                           points, N, H, W, h_up, h_down, zb, winner);
+        hipLaunchKernelGGL(project64_scatter_kernel<1>, dim3((N + 255) / 256), dim3(256), 0, lc_s(s),
+                           points, N, H, W, h_up, h_down, zb, winner);
+    }
+    hipLaunchKernelGGL(project64_gather_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
                        HW, zb, min_depth, max_depth, image, winner);
     return lc_launch_status();
 }

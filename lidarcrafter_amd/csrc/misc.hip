@@ -144,7 +144,7 @@ inline int grid_for(long long n) {
 
 }  // namespace
 
-extern "C" int lc_abi_version(void) { return 1; }
+extern "C" int lc_abi_version(void) { return 2; }
 
 extern "C" int lc_device_arch(char* buf, int buflen) {
     if (!buf || buflen <= 0) return LC_EINVAL;

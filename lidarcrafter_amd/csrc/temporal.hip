@@ -29,6 +29,33 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(out + 4ll * i) = o;
 }
 
+// float64 rows out (round 3): the reference keeps `(Ts @ homo_pts.T).T` as a float64 array and
+// projects it in float64 (pipe_related.py:245-257 -> common.py:41-91), so the moved background is
+// NOT rounded here.  rot_f32 = 1: out.xyz = (double)(float)(R p) + t -- the re-posed object points
+// `rotate_points_along_z(p, yaw)` (a float32 matmul, dataset/utils.py:37-59; its library-defined
+// summation order is replaced by the correctly rounded value) `+ np.array([x, y, z])` (float64,
+// pipe_related.py:263-266).
+struct f64x4 { double x, y, z, w; };
+__global__ __launch_bounds__(256) void transform64_kernel(const float* __restrict__ pts, int N, Affine T,
+                                                         int rot_f32, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pts + 4ll * i);
+    const double x = p.x, y = p.y, z = p.z;
+    f64x4 o;
+    if (rot_f32) {
+        o.x = (double)(float)((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+        o.y = (double)(float)((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+        o.z = (double)(float)((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+    } else {
+        o.x = ((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3];
+        o.y = ((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7];
+        o.z = ((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11];
+    }
+    o.w = (double)p.w;
+    *reinterpret_cast<f64x4*>(out + 4ll * i) = o;
+}
+
 // xyz [3,H,W] planes (+ reflectance plane) -> rows (x, y, z, refl * refl_scale), multiplied by
 // the background mask !(cond[h,w] > 0) when `cond` is given; keep[i] = 1 unless
 //   |p.xyz| <= min_norm            (min_norm >= 0; the reference drops the zeroed pixels), or
@@ -143,6 +170,18 @@ extern "C" int lc_transform_points(const float* pts, int N, const double* T16, f
     Affine T;
     for (int i = 0; i < 12; ++i) T.m[i] = T16[i];
     hipLaunchKernelGGL(transform_kernel, dim3((N + 255) / 256), dim3(256), 0, lc_s(s), pts, N, T, out);
+    return lc_launch_status();
+}
+
+extern "C" int lc_transform_points_f64(const float* pts, int N, const double* T16, int rot_f32,
+                                       double* out, lc_stream_t s) {
+    if (N < 0 || !T16 || (N > 0 && (!pts || !out))) return LC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(pts) & 15) || (reinterpret_cast<uintptr_t>(out) & 31)) return LC_EINVAL;
+    if (N == 0) return LC_OK;
+    Affine T;
+    for (int i = 0; i < 12; ++i) T.m[i] = T16[i];
+    hipLaunchKernelGGL(transform64_kernel, dim3((N + 255) / 256), dim3(256), 0, lc_s(s), pts, N, T,
+                       rot_f32 ? 1 : 0, out);
     return lc_launch_status();
 }
 

@@ -110,8 +110,11 @@ class CustomDataset:
                                    cls.reshape(-1, 1).astype(np.float32)), axis=1)
         data_dict["gt_boxes"] = gt_boxes
         dev = torch.device("cuda", torch.cuda.current_device())
+        # the reference's dtype flow follows the boxes: float64 `gt_boxes` (every caller on the path:
+        # python lists / float64 arrays + the float32 class column) -> all-float64 geometry
+        bdt = np.float64 if gt_boxes.dtype == np.float64 else np.float32
         b2d, cond, wmap = common.convert_boxes_to_2d(
-            torch.from_numpy(np.ascontiguousarray(gt_boxes, np.float32)).to(dev), H=H, W=W,
+            torch.from_numpy(np.ascontiguousarray(gt_boxes, bdt)).to(dev), H=H, W=W,
             min_depth=self.cfg.min_depth, max_depth=self.cfg.max_depth, fov_up=self.cfg.fov_up,
             fov_down=self.cfg.fov_down)
         scaled = self.scale_boxes_3d(gt_boxes.copy())
@@ -128,8 +131,12 @@ class CustomDataset:
             H, W = self.cfg.resolution
             pts = d["points"]
             if not isinstance(pts, torch.Tensor):
-                pts = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
-            img = common.load_points_as_images(points=pts.float().contiguous(), scan_unfolding=False,
+                pts = torch.from_numpy(np.ascontiguousarray(
+                    pts, np.float64 if pts.dtype == np.float64 else np.float32)).cuda()
+            elif pts.dtype != torch.float64:
+                pts = pts.float()
+            # float64 point sets (the temporal glue's) are projected in float64, like the reference
+            img = common.load_points_as_images(points=pts.contiguous(), scan_unfolding=False,
                                                H=H, W=W, min_depth=self.cfg.min_depth,
                                                max_depth=self.cfg.max_depth, fov_up=self.cfg.fov_up,
                                                fov_down=self.cfg.fov_down)

@@ -36,8 +36,11 @@ def load_points_as_images(point_path: str = None, points=None, scan_unfolding: b
     is_numpy = isinstance(points, np.ndarray)
     if not torch.cuda.is_available():
         raise RuntimeError("load_points_as_images needs the MI355X: no CPU fallback on the hot path")
-    p = torch.from_numpy(np.ascontiguousarray(points[:, :4], np.float32)) if is_numpy else points
-    p = p[:, :4].float().contiguous().cuda()
+    # float64 points (the temporal glue's promoted sets) are projected in float64 like the reference
+    f64 = (points.dtype == np.float64) if is_numpy else (points.dtype == torch.float64)
+    p = torch.from_numpy(np.ascontiguousarray(points[:, :4], np.float64 if f64 else np.float32)) \
+        if is_numpy else points
+    p = p[:, :4].to(torch.float64 if f64 else torch.float32).contiguous().cuda()
     img, _ = K.project_points(p, H, W, fov_up, fov_down, min_depth, max_depth)
     return img.cpu().numpy() if is_numpy else img
 
@@ -51,8 +54,12 @@ def convert_boxes_to_2d(boxes_3d, H: int = 64, W: int = 2048, min_depth: float =
     is_numpy = isinstance(boxes_3d, np.ndarray)
     if not torch.cuda.is_available():
         raise RuntimeError("convert_boxes_to_2d needs the MI355X: no CPU fallback on the hot path")
-    b = torch.from_numpy(np.ascontiguousarray(boxes_3d, np.float32)) if is_numpy else boxes_3d
-    b = b.float().contiguous().cuda()[None]
+    # float64 boxes (NuscDataset.pre_process hands them over, nuscenes_dataset.py:384-397) keep the
+    # reference's all-float64 flow; anything else follows its float32 flow
+    f64 = (boxes_3d.dtype == np.float64) if is_numpy else (boxes_3d.dtype == torch.float64)
+    b = torch.from_numpy(np.ascontiguousarray(boxes_3d, np.float64 if f64 else np.float32)) \
+        if is_numpy else boxes_3d
+    b = b.to(torch.float64 if f64 else torch.float32).contiguous().cuda()[None]
     n = torch.tensor([b.shape[1]], dtype=torch.int32, device=b.device)
     c2d, mask, wmap = K.layout_condition(b, n, H, W, fov_up, fov_down, with_weight_map=True)
     c2d, mask, wmap = c2d[0], mask[0], wmap[0]

@@ -36,6 +36,11 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     # several sample() calls -- generate_sequence passes one `rng` to every frame -- ends in the
     # state a seeded reference run leaves it in.  rng=None (the process-global generator, whose
     # stream differs between CPU and GPU anyway) is not advanced.  False skips the draw always.
+    # Inside `sample()` the draws are DEFERRED: the loop only counts them and `finish_sampling`
+    # makes them after the last step has been enqueued, i.e. while the GPU is still working through
+    # the replayed steps (K separate draws of the same shape leave a generator in the same state
+    # wherever they happen) -- B full-frame CPU randn calls per step would otherwise sit on the
+    # critical path of a ~1-4 ms step.
     advance_rng_when_unused = True
 
     def __init__(self, model: nn.Module, condition_model: nn.Module = None,
@@ -109,15 +114,31 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     def _clip(self):
         return float(self.clip_sample_range) if self.clip_sample else 0.0
 
-    def _noise_for(self, x_t, rng, mode, ddim_eta):
+    def _noise_for(self, x_t, rng, mode, ddim_eta, st=None):
         if mode == "ddpm" or ddim_eta != 0.0:
             return self.randn_like(x_t, rng=rng)
         if self.advance_rng_when_unused and rng is not None:
-            gens = [rng] if isinstance(rng, torch.Generator) else rng
-            shape = x_t.shape if isinstance(rng, torch.Generator) else x_t.shape[1:]
+            if st is not None:                       # inside a sampling run: see finish_sampling
+                st["unused_draws"] = st.get("unused_draws", 0) + 1
+            else:
+                self._discard_draws(x_t, rng, 1)
+        return None
+
+    @staticmethod
+    def _discard_draws(x_t, rng, count):
+        gens = [rng] if isinstance(rng, torch.Generator) else rng
+        shape = x_t.shape if isinstance(rng, torch.Generator) else x_t.shape[1:]
+        for _ in range(count):
             for g in gens:
                 torch.randn(*shape, generator=g, device=g.device, dtype=x_t.dtype)
-        return None
+
+    def finish_sampling(self, st: dict) -> None:
+        """Make the generator draws the loop deferred (DDIM eta = 0 with explicit generators).
+        `sample()` calls it; users of the step-wise API call it after their last `sampling_step`
+        when they share the generators with later runs."""
+        n = st.pop("unused_draws", 0)
+        if n:
+            self._discard_draws(st["x"], st["rng"], n)
 
     def _predict(self, x_t, log_snr_t, time_features=None):
         if time_features is not None:
@@ -236,7 +257,7 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     def _sampling_step(self, st: dict) -> torch.Tensor:
         i, B, x = st["i"], st["B"], st["x"]
         tf = None if st["tf"] is None else tuple(a[i * B:(i + 1) * B] for a in st["tf"])
-        noise = self._noise_for(x, st["rng"], st["mode"], st["eta"])
+        noise = self._noise_for(x, st["rng"], st["mode"], st["eta"], st)
         graphable = (self.use_hip_graph and x.is_cuda and K.PROFILE is None and st["n"] > 2)
         if graphable and i >= 1:
             if st.get("graph") is None:
@@ -272,6 +293,7 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
                 x = self.sampling_step(st)
                 if return_all:
                     out.append(x.clone())
+            self.finish_sampling(st)
             return torch.stack(out) if return_all else st["x"].clone()
 
         # the conv range records are polled ONCE, after the loop; a run in which a layer's fp16

@@ -72,6 +72,7 @@ class CondContinuousTimeGaussianDiffusion(continuous_time.ContinuousTimeGaussian
                 x = self.sampling_step(st)
                 if return_all:
                     out.append(x.clone())
+            self.finish_sampling(st)
             return torch.stack(out) if return_all else st["x"].clone()
 
         return K.run_range_safe(run, rng, self.device, "CondContinuousTimeGaussianDiffusion.sample")

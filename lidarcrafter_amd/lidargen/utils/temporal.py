@@ -189,17 +189,20 @@ def get_temporal_boxes_3d(first_frame_data_dict, M=None):
 
 def get_next_frame_points(curr_background_points, align_obj_points, align_obj_intensity,
                           fut_boxes_3d, fut_boxes_names, Ts):
-    """Background moved by Ts and re-projected + every object re-posed in its future box."""
-    fut_bg = K.transform_points(curr_background_points.contiguous(), Ts)
+    """Background moved by Ts and re-projected + every object re-posed in its future box --
+    pipe_related.py:243-269 with the reference's dtypes: the moved background is a FLOAT64 set
+    (`Ts @ homo`) that `refine_next_frame_points` projects in float64 (float32 rows come back);
+    the objects are `float32 rotation + float64 centre`; the result is the float64 concatenation."""
+    fut_bg = K.transform_points(curr_background_points.float().contiguous(), Ts, f64="keep")
     fut_bg = refine_next_frame_points([{
         "points": fut_bg, "gt_boxes": np.concatenate([np.zeros((1, 7)), fut_boxes_3d]),
         "gt_names": fut_boxes_names}])
-    parts = [fut_bg]
+    parts = [fut_bg.double()]
     for k, box in enumerate(fut_boxes_3d):
         if align_obj_points[k].shape[0] == 0:
             continue
         p = torch.cat([align_obj_points[k], align_obj_intensity[k][:, None]], dim=1).contiguous()
-        parts.append(K.transform_points(p, _box_frame(box, inverse=True)))
+        parts.append(K.transform_points(p, _box_frame(box, inverse=True), f64="rot32"))
     return torch.cat(parts, dim=0)
 
 

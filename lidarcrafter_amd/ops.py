@@ -254,7 +254,14 @@ _A_RECAL_HI = 2.0 ** 15        # within 2x of saturation: move the scale (result
 _A_INVALID_LO = 2.0 ** -3      # error relative to max|x| exceeds the split's own 2^-22
 _A_RECAL_LO = 2.0 ** 2
 _range_arenas = {}
-_range_defer = 0
+import threading as _threading
+
+
+class _Defer(_threading.local):
+    depth = 0
+
+
+_range_defer = _Defer()          # per thread: a sampler thread's deferral does not silence another's
 
 
 class ConvRangeError(ArithmeticError):
@@ -272,6 +279,9 @@ class _RangeArena:
             init[:, 0], init[:, 1] = X_SCALE_DEFAULT, 1.0 / X_SCALE_DEFAULT
             self.buf = init.to(device)
         self.scale = [X_SCALE_DEFAULT] * RANGE_SLOTS      # host mirror of x_scale
+        # slots whose x_scale is (re)written ON THE DEVICE (lc_range_from_tensor, the training
+        # graph): the host mirror is meaningless for them and the poll leaves them alone
+        self.device_managed = set()
         self.free = list(range(RANGE_SLOTS - 1, -1, -1))
         self.owner = {}                                    # slot -> weakref to the owning PackedConv
         with torch.inference_mode(False):
@@ -286,6 +296,7 @@ class _RangeArena:
             raise RuntimeError("range arena exhausted (more than 4096 live conv layers)")
         slot = self.free.pop()
         self.owner[slot] = weakref.ref(owner)
+        self.device_managed.discard(slot)
         # a recycled slot starts clean: a running maximum left by its previous owner would hide
         # the new layer's (smaller) values from the poll
         self.scale[slot] = X_SCALE_DEFAULT
@@ -365,7 +376,7 @@ def range_poll(device=None, quiet: bool = True):
     for slot in hot.flatten().tolist():
         ref = a.owner.get(slot)
         owner = ref() if ref is not None else None
-        if owner is None:
+        if owner is None or slot in a.device_managed:
             continue
         A = float(am[slot])
         old = a.scale[slot]
@@ -442,12 +453,10 @@ class defer_range_checks:
     end of the run instead)."""
 
     def __enter__(self):
-        global _range_defer
-        _range_defer += 1
+        _range_defer.depth += 1
 
     def __exit__(self, *exc):
-        global _range_defer
-        _range_defer -= 1
+        _range_defer.depth -= 1
         return False
 
 
@@ -460,8 +469,14 @@ def range_checked(forward):
     @functools.wraps(forward)
     def wrapper(self, *args, **kw):
         x = args[0] if args else None
-        if _range_defer > 0 or CONV_PRECISION != "f16x2" or not isinstance(x, torch.Tensor) or \
+        if _range_defer.depth > 0 or CONV_PRECISION != "f16x2" or not isinstance(x, torch.Tensor) or \
                 not x.is_cuda or torch.cuda.is_current_stream_capturing():
+            return forward(self, *args, **kw)
+        if torch.is_grad_enabled() and (x.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            # training graph: every operand's pre-scale is measured on the device right before
+            # its conv (range_from_tensor), so nothing can be invalid -- and a poll would be a
+            # blocking device->host copy per step, a retry a second graph with new dropout masks
             return forward(self, *args, **kw)
         for _ in range(5):
             out = forward(self, *args, **kw)
@@ -515,6 +530,22 @@ class PackedConv:
         self.name = name
         self._slot = self._arena = None
 
+    # A copy (copy.deepcopy(model) -- what ema_pytorch's EMA(ddpm) in the reference trainers does --
+    # or pickling, torch.save(model)) is a FRESH PackedConv: it owns no arena slot and no packed
+    # caches, so it lazily allocates its own slot in the REGISTERED arena of its device and its
+    # amax is polled like any other layer's.  (Copying the fields would clone the whole arena into a
+    # private object `range_poll` never reads and share the slot index with the original.)
+    def __deepcopy__(self, memo):
+        new = PackedConv(self.name)
+        memo[id(self)] = new
+        return new
+
+    def __copy__(self):
+        return PackedConv(self.name)
+
+    def __reduce__(self):
+        return (PackedConv, (self.name,))
+
     def range_ptr(self, device) -> int:
         if self._arena is None or self._arena.device != device:
             if self._arena is not None:
@@ -525,7 +556,11 @@ class PackedConv:
 
     @property
     def x_scale(self) -> float:
-        return X_SCALE_DEFAULT if self._arena is None else self._arena.scale[self._slot]
+        if self._arena is None:
+            return X_SCALE_DEFAULT
+        if self._slot in self._arena.device_managed:      # the truth lives on the device
+            return float(self._arena.buf[self._slot, 0])
+        return self._arena.scale[self._slot]
 
     def __del__(self):
         try:
@@ -586,8 +621,9 @@ def range_from_tensor(x: torch.Tensor, packed: PackedConv) -> None:
     else:
         x = x if x.is_contiguous() else x.contiguous()
         x_bs = n
-    check(lib().lc_range_from_tensor(x.data_ptr(), x_bs, B, n, packed.range_ptr(x.device), _stream()),
-          "lc_range_from_tensor")
+    ptr = packed.range_ptr(x.device)
+    packed._arena.device_managed.add(packed._slot)
+    check(lib().lc_range_from_tensor(x.data_ptr(), x_bs, B, n, ptr, _stream()), "lc_range_from_tensor")
 
 
 def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
@@ -1112,6 +1148,21 @@ def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down
     mode = dtype_mode or PROJECTION_DTYPE
     if mode not in ("native", "f32"):
         raise ValueError(f"projection dtype mode {mode!r}")
+    if isinstance(points, torch.Tensor) and points.is_cuda and points.dtype == torch.float64:
+        # float64 point sets of the temporal glue: the reference projects them in float64
+        if return_cells:
+            raise ValueError("project_points: return_cells is not available for float64 points")
+        if points.dim() != 2 or points.shape[1] != 4 or not points.is_contiguous():
+            raise ValueError("project_points: points must be contiguous [N,4]")
+        N, dev = points.shape[0], points.device
+        zbuf = torch.empty(H * W, device=dev, dtype=torch.int64)
+        img = torch.empty((H, W, 6), device=dev, dtype=_F32)
+        win = torch.empty((H, W), device=dev, dtype=torch.int32)
+        check(lib().lc_project_points_f64(points.data_ptr(), N, H, W, float(fov_up), float(fov_down),
+                                          float(min_depth), float(max_depth), zbuf.data_ptr(),
+                                          win.data_ptr(), img.data_ptr(), _stream()),
+              "lc_project_points_f64")
+        return img, win
     _req(points, "points")
     if points.dim() != 2 or points.shape[1] != 4 or not points.is_contiguous():
         raise ValueError("project_points: points must be contiguous [N,4]")
@@ -1158,9 +1209,13 @@ def _pts4(t: torch.Tensor, name: str) -> int:
     return t.shape[0]
 
 
-def transform_points(points: torch.Tensor, T, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def transform_points(points: torch.Tensor, T, out: Optional[torch.Tensor] = None,
+                     f64: Optional[str] = None) -> torch.Tensor:
     """[N,4] rows (x,y,z,intensity) -> (T[:3,:3] p + T[:3,3], intensity); T: 4x4 host matrix
-    (numpy / nested list / CPU tensor), product in fp64 rounded once (pipe_related.py:245-249)."""
+    (numpy / nested list / CPU tensor), product in fp64 rounded once (pipe_related.py:245-249).
+    f64 = "keep": float64 rows out, not rounded (the reference's float64 `Ts @ homo`);
+    f64 = "rot32": float64 rows (double)(float)(R p) + t (float32 rotation + float64 centre,
+    pipe_related.py:263-266)."""
     import ctypes as C
     import numpy as np
 
@@ -1168,6 +1223,14 @@ def transform_points(points: torch.Tensor, T, out: Optional[torch.Tensor] = None
     T = np.ascontiguousarray(np.asarray(T, dtype=np.float64))
     if T.shape != (4, 4):
         raise ValueError("transform_points: T must be 4x4")
+    if f64 is not None:
+        if f64 not in ("keep", "rot32") or out is not None:
+            raise ValueError("transform_points: f64 must be 'keep' or 'rot32' (no out=)")
+        o64 = torch.empty((N, 4), device=points.device, dtype=torch.float64)
+        check(lib().lc_transform_points_f64(points.data_ptr(), N, T.ctypes.data_as(C.POINTER(C.c_double)),
+                                            1 if f64 == "rot32" else 0, o64.data_ptr(), _stream()),
+              "lc_transform_points_f64")
+        return o64
     if out is None:
         out = torch.empty_like(points)
     elif _pts4(out, "out") != N:
@@ -1433,8 +1496,11 @@ def condition_preprocess(condition_mask: torch.Tensor, num_classes: int, depth_f
 def layout_condition(boxes: torch.Tensor, n_valid: torch.Tensor, H: int, W: int, fov_up: float,
                      fov_down: float, with_weight_map: bool = False):
     """boxes [B,T,>=8] (x,y,z,l,w,h,yaw,class), n_valid int32 [B] -> (corners_2d [B,T,4],
-    condition_mask [B,2,H,W][, loss_weight_map [B,H,W]])."""
-    _req(boxes, "boxes")
+    condition_mask [B,2,H,W][, loss_weight_map [B,H,W]]).  float32 or float64 boxes: the kernel
+    follows the dtype flow numpy gives the reference for each (lc_layout_condition)."""
+    f64 = isinstance(boxes, torch.Tensor) and boxes.is_cuda and boxes.dtype == torch.float64
+    if not f64:
+        _req(boxes, "boxes")
     if boxes.dim() != 3 or boxes.shape[2] < 8 or not boxes.is_contiguous():
         raise ValueError("layout_condition: boxes must be contiguous [B,T,>=8]")
     if n_valid.dtype != torch.int32 or not n_valid.is_cuda:
@@ -1445,7 +1511,7 @@ def layout_condition(boxes: torch.Tensor, n_valid: torch.Tensor, H: int, W: int,
     c2d = torch.empty((B, T, 4), device=dev, dtype=_F32)
     mask = torch.empty((B, 2, H, W), device=dev, dtype=_F32)
     wmap = torch.empty((B, H, W), device=dev, dtype=_F32) if with_weight_map else None
-    check(lib().lc_layout_condition(boxes.data_ptr(), S, n_valid.data_ptr(), B, T, H, W,
+    check(lib().lc_layout_condition(boxes.data_ptr(), int(f64), S, n_valid.data_ptr(), B, T, H, W,
                                     float(fov_up), float(fov_down), scratch.data_ptr(),
                                     c2d.data_ptr(), mask.data_ptr(), _p(wmap), _stream()),
           "lc_layout_condition")

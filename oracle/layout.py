@@ -2,25 +2,29 @@
 
 Follows /root/reference/lidargen/dataset/transforms_3d/common.py: rotz :93-97,
 convert_boxes_to_2d :99-181, convert_points_to_2d :184-215 with the dtypes the reference ends up
-with for float32 boxes: cos/sin of the yaw in float32, corner geometry in float64, centre depth in
-float32.  Pinned by tests/golden/layout_cond.npz (the reference's own output)."""
+with: for float32 boxes cos/sin of the yaw in float32, corner geometry in float64, centre depth in
+float32 (pinned by tests/golden/layout_cond.npz, the reference's own output); for float64 boxes --
+what `NuscDataset.pre_process` hands over (nuscenes_dataset.py:384-386: float64 `gt_boxes` with the
+class column appended) -- everything in float64, the centre depth rounded to float32 only when it is
+painted (pinned by tests/golden/pipe_next.npz, the reference's own CustomDataset item)."""
 from __future__ import annotations
 
 import numpy as np
 
 
 def box_rectangles(boxes: np.ndarray, H: int, W: int, fov_up=10.0, fov_down=-30.0):
-    """boxes float32 [n, >=7] -> (corners_2d float64 [n,4] (x1,y1,x2,y2 normalised),
+    """boxes float32 / float64 [n, >=7] -> (corners_2d float64 [n,4] (x1,y1,x2,y2 normalised),
     rect int [n,4] (x1,y1,x2,y2 pixels), wrap bool [n], depth float32 [n])."""
-    b = boxes.astype(np.float32)
+    f64 = np.asarray(boxes).dtype == np.float64
+    b = np.asarray(boxes, np.float64 if f64 else np.float32)
     n = len(b)
     l, w, h = b[:, 3].astype(np.float64), b[:, 4].astype(np.float64), b[:, 5].astype(np.float64)
     sx = np.array([1, 1, -1, -1, 1, 1, -1, -1]) * 0.5
     sy = np.array([1, -1, -1, 1, 1, -1, -1, 1]) * 0.5
     sz = np.array([1, 1, 1, 1, -1, -1, -1, -1]) * 0.5
     X, Y, Z = l[:, None] * sx, w[:, None] * sy, h[:, None] * sz
-    c = np.cos(b[:, 6]).astype(np.float32).astype(np.float64)[:, None]   # float32 cos, see header
-    s = np.sin(b[:, 6]).astype(np.float32).astype(np.float64)[:, None]
+    c = np.cos(b[:, 6]).astype(b.dtype).astype(np.float64)[:, None]   # float32 cos for float32 boxes
+    s = np.sin(b[:, 6]).astype(b.dtype).astype(np.float64)[:, None]
     cx, cy, cz = (b[:, k].astype(np.float64)[:, None] for k in range(3))
     px, py, pz = c * X - s * Y + cx, s * X + c * Y + cy, Z + cz
     depth = np.sqrt(px * px + py * py + pz * pz) + 1e-6
@@ -35,7 +39,7 @@ def box_rectangles(boxes: np.ndarray, H: int, W: int, fov_up=10.0, fov_down=-30.
     wrap = (rect[:, 2] - rect[:, 0]) / W > 0.6
     xyz = b[:, :3]
     cdep = np.sqrt((xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]) + xyz[:, 2] * xyz[:, 2]) + \
-        np.float32(1e-6)
+        b.dtype.type(1e-6)
     return c2d, rect, wrap, cdep.astype(np.float32)
 
 

@@ -807,8 +807,9 @@ def test_transform_points_bit_exact(dev, golden):
 from tests._scenes import temporal_scene as _temporal_scene  # noqa: E402
 
 
-def test_custom_dataset_item_vs_unpinned_restatement(dev):
-    """CustomDataset.__getitem__ + pre_process on the device vs the oracle restatement."""
+def test_custom_dataset_item_vs_oracle(dev):
+    """CustomDataset.__getitem__ + pre_process on the device vs the oracle (itself pinned on the
+    reference's own CustomDataset, tests/golden/pipe_next.npz): float32 and float64 point sets."""
     import lidargen  # noqa: F401
     from lidargen.dataset import __all__ as DS
     from oracle import temporal as OT
@@ -816,7 +817,7 @@ def test_custom_dataset_item_vs_unpinned_restatement(dev):
     first, pts, ref = _temporal_scene(3)
     ds = DS["custom"]([dict(points=pts, gt_boxes=first["gt_boxes"].copy(), gt_names=first["gt_names"])])
     it = ds[0]
-    for k in ("xyz", "reflectance", "depth", "mask", "condition_mask"):
+    for k in ("xyz", "reflectance", "depth", "mask", "condition_mask", "scene_loss_weight_map"):
         assert np.array_equal(it[k].cpu().numpy(), ref[k]), k
     for k in ("scaled_gt_boxes", "gt_boxes_2d", "fg_encoding_box", "is_valid_obj"):
         assert np.allclose(np.asarray(it[k]), ref[k], rtol=1e-6, atol=1e-6), k
@@ -828,12 +829,136 @@ def test_custom_dataset_item_vs_unpinned_restatement(dev):
     batch = ds.collate_fn([it2, ds[0]])
     assert batch["autoregressive_cond"].shape == (2, 2, 32, 1024) and batch["batch_size"] == 2
     assert batch["scaled_gt_boxes"].shape == (2, 13, 9) and batch["is_valid_obj"].shape == (2, 13)
+    # float64 points: projected in float64 (numpy and device-tensor inputs)
+    p64 = pts.astype(np.float64) * 1.0000001
+    ref3 = OT.custom_item(p64, first["gt_boxes"].copy(), first["gt_names"], task="autoregressive_generation")
+    for src in (p64, torch.from_numpy(p64).to(dev)):
+        ds3 = DS["custom"]([dict(points=src, gt_boxes=first["gt_boxes"].copy(), gt_names=first["gt_names"])])
+        ds3.task = "autoregressive_generation"
+        assert np.array_equal(ds3[0]["autoregressive_cond"].cpu().numpy(), ref3["autoregressive_cond"])
+
+
+def test_custom_dataset_item_vs_reference_golden(dev, golden):
+    """The device item vs outputs of the REFERENCE's own CustomDataset.__getitem__ /
+    NuscDataset.pre_process (tests/golden/pipe_next.npz): images bit-identical outside the <= 2
+    cells a float32 asin / atan2 last-bit-ambiguous point can reach (numpy's float32 ufuncs are not
+    correctly rounded), everything else bit-identical; float64 point sets and the
+    boxes-only item bit-identical."""
+    import lidargen  # noqa: F401
+    from lidargen.dataset.custom_dataset import CustomDataset
+    from oracle import lidar as OLD
+
+    g = golden("pipe_next")
+    for seed in (0, 1):
+        first, pts, _ = _temporal_scene(seed)
+        t = f"s{seed}_"
+        info = lambda p: dict(points=p, gt_boxes=first["gt_boxes"].copy(), gt_names=list(first["gt_names"]))
+        it = CustomDataset([info(pts.copy())])[0]
+        assert sorted(it.keys()) == list(g[t + "item_keys"])
+        _, cells = OLD.ulp_ambiguous(pts, 32, 1024, 10.0, -30.0)
+        free = np.ones((32, 1024), bool)
+        for (r, c) in cells:
+            free[r, c] = False
+        for k in ("xyz", "reflectance", "depth", "mask", "condition_mask", "scene_loss_weight_map"):
+            if t + "item_" + k not in g:
+                continue
+            a, ref = it[k].cpu().numpy(), g[t + "item_" + k]
+            assert a.dtype == ref.dtype and a.shape == ref.shape, k
+            if k in ("condition_mask", "scene_loss_weight_map"):
+                assert np.array_equal(a, ref), k
+            else:
+                assert np.array_equal(a[..., free], ref[..., free]), k
+        for k in ("gt_boxes", "scaled_gt_boxes", "gt_boxes_2d", "fg_encoding_box", "is_valid_obj"):
+            assert np.allclose(np.asarray(it[k], np.float64), g[t + "item_" + k], rtol=0, atol=1e-12), k
+        p64 = pts.astype(np.float64) * 1.0000001
+        ds = CustomDataset([info(p64.copy())])
+        i64 = ds[0]
+        ds.task = "autoregressive_generation"
+        iar = ds[0]
+        assert sorted(iar.keys()) == list(g[t + "itemar_keys"])
+        if seed == 0:
+            assert np.array_equal(i64["xyz"].cpu().numpy(), g[t + "item64_xyz"])
+            assert np.array_equal(iar["autoregressive_cond"].cpu().numpy(), g[t + "itemar_cond"])
+        else:
+            wts = np.arange(1, 2 * 32 * 1024 + 1, dtype=np.float64).reshape(2, 32, 1024)
+            dig = np.array([float((iar["autoregressive_cond"].cpu().numpy() * wts).sum()),
+                            float(np.abs(i64["xyz"].cpu().numpy()).sum(dtype=np.float64))])
+            assert np.array_equal(dig, g[t + "itemar_cond_digest"])
+        itb = CustomDataset([dict(gt_boxes=first["gt_boxes"].copy(), gt_names=list(first["gt_names"]))])[0]
+        assert sorted(itb.keys()) == list(g[t + "itemb_keys"])
+        assert np.array_equal(itb["condition_mask"].cpu().numpy(), g[t + "itemb_condition_mask"])
+
+
+def test_next_frame_points_vs_reference_golden(dev, golden):
+    """refine_next_frame_points / get_next_frame_points on the device vs outputs of the REFERENCE's
+    own pipe_related.py run through its own CustomDataset (tests/golden/pipe_next.npz), chained over
+    two future frames like sample_and_save_temporal.py:296-327.  Each call gets the inputs the
+    reference's call got (rebuilt with the oracle's reference flow, which the CPU suite proves
+    bit-exact): the re-projected background -- float64 `Ts @ homo`, float64 projection, mask,
+    compaction -- is BIT-IDENTICAL (count, order, values); the re-posed object rows (the
+    reference's float32 library matmuls vs correctly rounded values) agree to two float32 ulps."""
+    import lidargen  # noqa: F401
+    from lidargen.utils import temporal as T
+    from oracle import temporal as OT
+
+    g = golden("pipe_next")
+    for seed in (0, 1):
+        first, pts, _ = _temporal_scene(seed)
+        t = f"s{seed}_"
+        rfirst = dict(first)
+        rfirst["xyz"], rfirst["reflectance"] = g[t + "item_xyz"], g[t + "item_reflectance"]
+        _, rfut_bg, _, fut_boxes, Ts, robj_pts, robj_int = OT.get_temporal_boxes_3d(rfirst, f32=False)
+        dfirst = dict(rfirst)
+        for k in ("xyz", "reflectance", "condition_mask"):
+            dfirst[k] = torch.from_numpy(np.ascontiguousarray(rfirst[k])).to(dev)
+        _, fut_bg, _, dfut_boxes, dTs, obj_pts, obj_int = T.get_temporal_boxes_3d(dfirst)
+        assert np.allclose(dfut_boxes, g[t + "fut_boxes"], rtol=0, atol=1e-11)
+        assert np.allclose(dTs, g[t + "Ts"], rtol=0, atol=1e-11)
+        xyz, refl = rfirst["xyz"], rfirst["reflectance"]
+        cur = np.stack([xyz[0], xyz[1], xyz[2], refl[0]], -1).reshape(-1, 4)
+        dcur_chain = torch.from_numpy(cur).to(dev)
+        for f in range(2):
+            ref = g[t + f"next{f}"]
+            n = int(g[t + f"refine{f}_n"][0])
+            dcur = torch.from_numpy(np.ascontiguousarray(cur, np.float32)).to(dev)
+            moved = K.transform_points(dcur, Ts[f], f64="keep")
+            assert moved.dtype == torch.float64
+            rbg = T.refine_next_frame_points([dict(
+                points=moved, gt_boxes=np.concatenate([np.zeros((1, 7)), fut_boxes[:, f]]),
+                gt_names=list(first["gt_names"]))])
+            assert rbg.dtype == torch.float32 and np.array_equal(rbg.cpu().numpy(), ref[:n])
+            nxt = T.get_next_frame_points(dcur, obj_pts, obj_int, fut_boxes[:, f],
+                                          list(first["gt_names"]), Ts[f])
+            assert nxt.dtype == torch.float64 and tuple(nxt.shape) == ref.shape
+            a = nxt.cpu().numpy()
+            assert np.array_equal(a[:n], ref[:n])
+            assert ref.shape[0] - n > 1000 and np.abs(a[n:] - ref[n:]).max() <= 1.6e-5
+            assert np.array_equal(a[n:, 3], ref[n:, 3])
+            # the same call on the reference's own float32 object points: only the float32
+            # rotation of get_next_frame_points itself is left between the two -> one ulp
+            nx2 = T.get_next_frame_points(
+                dcur, [torch.from_numpy(p).to(dev) for p in robj_pts],
+                [torch.from_numpy(i).to(dev) for i in robj_int], fut_boxes[:, f],
+                list(first["gt_names"]), Ts[f]).cpu().numpy()
+            assert np.abs(nx2[n:] - ref[n:]).max() <= 7.7e-6
+            gen = synth_points(32 * 1024, seed=300 + 10 * seed + f)
+            cur = OT.delete_fg_points(np.concatenate([rfut_bg[f], gen], axis=0), fut_boxes[:, f])
+            assert cur.dtype == np.float32 and cur.shape[0] == int(g[t + f"cur{f}_n"][0])
+            # device-only chain: every stage on the device, never re-seeded from the oracle
+            dnx = T.get_next_frame_points(dcur_chain, obj_pts, obj_int, fut_boxes[:, f],
+                                          list(first["gt_names"]), Ts[f])
+            assert abs(dnx.shape[0] - ref.shape[0]) <= 8
+            comb = torch.cat([fut_bg[f], torch.from_numpy(gen).to(dev)], dim=0).contiguous()
+            dcur_chain = T.delete_fg_points(comb, fut_boxes[:, f])
+            assert abs(dcur_chain.shape[0] - cur.shape[0]) <= 8
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_temporal_frame_glue_vs_unpinned_restatement(dev, seed):
+def test_temporal_frame_glue_vs_oracle(dev, seed):
     """get_temporal_boxes_3d -> get_next_frame_points -> delete_fg_points for two frames, device
-    vs oracle: identical point selections and order, coordinates bit-equal (same float64 4x4s)."""
+    vs the oracle's device-contract flow (oracle/temporal.py header; the oracle's reference flow is
+    pinned bit-exactly on the reference's outputs): identical point selections and order,
+    coordinates bit-equal (same float64 4x4s)."""
     import lidargen  # noqa: F401
     from lidargen.utils import temporal as T
     from oracle import temporal as OT
@@ -857,8 +982,10 @@ def test_temporal_frame_glue_vs_unpinned_restatement(dev, seed):
         nxt = T.get_next_frame_points(cur, obj_pts, obj_int, rfut_boxes[:, t], names, rTs[t])
         rnxt = OT.get_next_frame_points(rcur, robj_pts, robj_int, rfut_boxes[:, t], names, rTs[t])
         assert np.array_equal(nxt.cpu().numpy(), rnxt), t
-        comb = torch.cat([fut_bg[t], nxt], dim=0).contiguous()
-        rcomb = np.concatenate([rfut_bg[t], rnxt], axis=0)
+        assert nxt.dtype == torch.float64 and rnxt.dtype == np.float64
+        # (the rounded set stands in for the sampled frame, which is float32 in the reference)
+        comb = torch.cat([fut_bg[t], nxt.float()], dim=0).contiguous()
+        rcomb = np.concatenate([rfut_bg[t], rnxt.astype(np.float32)], axis=0)
         cur = T.delete_fg_points(comb, rfut_boxes[:, t])
         rcur = OT.delete_fg_points(rcomb, rfut_boxes[:, t])
         assert np.array_equal(cur.cpu().numpy(), rcur), t

@@ -167,3 +167,65 @@ def test_range_from_tensor_zero_input(dev):
     y = K.conv2d_ring(x, pk, torch.ones(16, 16, 3, 3, device=dev), precision="f16x2")
     assert float(y.abs().max()) == 0.0
     assert float(pk._arena.buf.view(-1, 4)[pk._slot][0]) == 16.0     # the default scale
+
+
+def test_deepcopied_model_keeps_the_range_guarantee(dev):
+    """`copy.deepcopy(model)` after a forward (ema_pytorch's EMA(ddpm) in the reference
+    trainers; any `torch.save(model)` round trip) must leave the copy's convolutions with their OWN
+    slots in the registered arena -- a saturating input to the copy is reported and recomputed, and
+    the original's records are untouched."""
+    import copy
+    import io
+
+    from lidarcrafter_amd import ops as K
+    from oracle import denoiser as D
+    from tests.test_hip_parity import _uncond
+
+    m = _uncond(16, (8, 64), dev)
+    with torch.no_grad():
+        m.in_conv.weight.mul_(1.0e-5)
+    x = seeded_randn(2, 2, 8, 64, seed=46)
+    lam = torch.tensor([-2.0, 1.0])
+    with torch.no_grad():
+        m(x.to(dev), lam.to(dev))                                  # slots allocated, caches built
+    pk0 = m.in_conv._packed
+    assert pk0._arena is not None
+    m2 = copy.deepcopy(m)
+    pk2 = m2.in_conv._packed
+    assert pk2 is not pk0 and pk2._arena is None and pk2.wh is None  # fresh, lazily allocated
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3.in_conv._packed._arena is None
+    sd = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+    big = x * 1.0e5
+    for mc in (m2, m3):
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            with torch.no_grad():
+                y = mc(big.to(dev), lam.to(dev))
+        assert any("in_conv" in str(w_.message) for w_ in rec), [str(w_.message) for w_ in rec]
+        assert rel_l2(y, D.efficient_unet_forward(sd, big, lam)) < 2e-5
+        pk = mc.in_conv._packed
+        assert pk._arena is K._arena(dev) and pk._slot != pk0._slot
+    assert pk0.x_scale == 16.0                                      # the original never saw `big`
+
+
+def test_training_forward_does_not_poll(dev, monkeypatch):
+    """the range-checked wrapper leaves the autograd path alone (no blocking
+    device->host copy per training step, no repeated graph)."""
+    from lidarcrafter_amd import ops as K
+    from tests.test_hip_parity import _uncond
+
+    m = _uncond(16, (8, 64), dev).train()
+    calls = []
+    real = K.range_poll
+    monkeypatch.setattr(K, "range_poll", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = seeded_randn(2, 2, 8, 64, seed=46).to(dev)
+    y = m(x, torch.tensor([-2.0, 1.0], device=dev))
+    y.square().mean().backward()
+    assert calls == []
+    with torch.no_grad():
+        m.eval()(x, torch.tensor([-2.0, 1.0], device=dev))
+    assert len(calls) == 1
