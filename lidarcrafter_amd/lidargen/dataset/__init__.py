@@ -4,7 +4,7 @@ import __all__` works, and constructing one says why it is unavailable.  `Custom
 (user-supplied boxes / points, the item builder of the temporal loop) and the
 projection every dataset calls per frame (transforms_3d.common.load_points_as_images) ARE on the
 path and run on the GPU."""
-from .custom_dataset import CustomDataset
+from .custom_dataset import CustomDataset, CustomNuscObjectDataset  # noqa: F401
 
 
 def _stub(name):

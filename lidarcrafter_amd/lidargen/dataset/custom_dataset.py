@@ -202,3 +202,20 @@ class CustomDataset:
                 ret[key] = val
         ret["batch_size"] = len(batch_list)
         return ret
+
+
+class NuscObjectConfig(DataConfig):
+    """custom_dataset.py:26-41 defaults."""
+    task = "object_generation"
+
+
+class CustomNuscObjectDataset(CustomDataset):
+    """custom_dataset.py:91-108: user-supplied boxes -> the foreground-object branch's condition
+    item (`fg_encoding_box` [K,6] in the unique-yaw encoding, `fg_class` [K]) -- host scalars only,
+    like the reference (<= 13 rows)."""
+
+    def __init__(self, custom_box_infos, cfg=None):
+        super().__init__(custom_box_infos, cfg if cfg is not None else NuscObjectConfig())
+
+    def __getitem__(self, idx):
+        return self.distille_local_boxes(self.data[idx])       # mutates + returns the entry, :105-108

@@ -12,8 +12,13 @@ names, argument meaning and return structure, with two differences:
     geometry.hip: affine transform, masked image -> point list, points-in-boxes, order-preserving
     compaction.  Box / trajectory arithmetic (<= 13 boxes x <= 16 steps of scalars) stays on the
     host in float64 numpy exactly as in the reference.
-  * dtype: the reference lets numpy promote the points to float64 between stages; here every
-    transform is evaluated in float64 and rounded once to the float32 row format.
+  * dtype: point sets the reference holds in float32 (frames, `warp_lidar_future` and
+    `rotate_points_along_z` results -- float32 library matmuls) are float32 rows, each transform
+    evaluated in float64 and rounded once; the sets it holds in FLOAT64 (`Ts @ homo`, the
+    [background | re-posed objects] concatenation) are float64 here too and are projected in
+    float64 (round 3; pinned on the reference's own outputs, tests/golden/pipe_next.npz).
+Also `conduct_obj_data_dict` :200-202 and `get_mask_cond_single` :220-227 (the condition items of
+the object branch / the layout-conditioned sampler from user boxes).
 """
 from __future__ import annotations
 
@@ -21,7 +26,7 @@ import numpy as np
 import torch
 
 from lidarcrafter_amd import ops as K
-from lidargen.dataset.custom_dataset import CustomDataset
+from lidargen.dataset.custom_dataset import CustomDataset, CustomNuscObjectDataset
 
 
 # ------------------------------------------------------------------------------ host (trajectories)
@@ -156,6 +161,21 @@ def refine_next_frame_points(cond_mask_dict_list):
     return _background_points(d["xyz"], d["reflectance"], d["condition_mask"])
 
 
+def conduct_obj_data_dict(unscaled_boxes_list):
+    """pipe_related.py:200-202: [{gt_boxes [1+K,7], gt_names}] -> the object branch's item."""
+    return CustomNuscObjectDataset(custom_box_infos=unscaled_boxes_list).__getitem__(0)
+
+
+def get_mask_cond_single(cond_mask_dict_list, temporal=False, inpaint=False):
+    """pipe_related.py:220-227: user boxes (+ points) -> the conditioning item of one frame."""
+    dataset = CustomDataset(custom_box_infos=cond_mask_dict_list)
+    if temporal:
+        setattr(dataset, "task", "autoregressive_generation")
+    if inpaint:
+        setattr(dataset, "inpaint_mode", True)
+    return dataset.__getitem__(0)
+
+
 def get_temporal_boxes_3d(first_frame_data_dict, M=None):
     """-> (curr_background_points, fut_background_points [T,N,4], curr_boxes_3d, fut_boxes_3d
     [K,T,7], Ts [T,4,4], align_obj_points list[K] of [n_k,3], align_obj_intensity list[K])."""
@@ -211,7 +231,8 @@ def get_next_frame_points(curr_background_points, align_obj_points, align_obj_in
 def generate_sequence(ddpm, auto_ddpm, lidar_utils, batch: dict, num_frames: int = 5,
                       num_steps: int = 256, mode: str = "ddpm", first_mode: str = None,
                       traj_length: int = 16, rng=None, num_classes: int = 9,
-                      auto_uses_reflectance: bool = False, data_cfg=None, progress: bool = False):
+                      auto_uses_reflectance: bool = False, data_cfg=None, progress: bool = False,
+                      trace: list = None):
     """Frame 0 from the layout-conditioned sampler, frames 1.. autoregressively -- the loop of
     tools/evaluation/sample_and_save_temporal.py:198-331 without its file output, every point set
     resident on the device.
@@ -221,7 +242,14 @@ def generate_sequence(ddpm, auto_ddpm, lidar_utils, batch: dict, num_frames: int
     the condition model reads) and per-sample lists `gt_boxes` ([1+K, >=7], ego row first),
     `gt_names`, `gt_fut_trajs` ([1+K, T, 2] per-step offsets, ego row first).
     Returns (frames, points): frames[t] = [B,5,H,W] (depth, x, y, z, reflectance) and
-    points[t][b] = the [H*W,4] (x,y,z,reflectance) rows of sample b at frame t."""
+    points[t][b] = the [H*W,4] (x,y,z,reflectance) rows of sample b at frame t.
+    `trace` (a list) receives one dict per autoregressive frame with the hand-overs of the loop
+    (`next_points` per sample, the collated `condition_mask` / raw `autoregressive_cond`, the
+    background sets the frame started from): what the parity tests feed to the oracle glue.
+    `data_cfg.resolution` is the resolution of the temporal CustomDataset items (the reference
+    always builds them at 32x1024 and resizes `autoregressive_cond` to the model's resolution with
+    nearest-exact interpolation, sample_and_save_temporal.py:133-148,177-179 -- done here too when
+    the two differ)."""
     dev = ddpm.device
     B = batch["condition_mask"].shape[0]
     cond_batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
@@ -263,10 +291,18 @@ def generate_sequence(ddpm, auto_ddpm, lidar_utils, batch: dict, num_frames: int
         tb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
         tb["concat_cond"] = lidar_utils.preprocess_condition_mask(tb["condition_mask"], num_classes)
         ar = tb["autoregressive_cond"]                       # [B,2,H,W]: metric depth, reflectance
+        if trace is not None:
+            trace.append(dict(t=t, next_points=[i["points"] for i in infos], cur_bg=list(cur_bg),
+                              gt_boxes=[i["gt_boxes"] for i in infos], Ts=[p["Ts"][t] for p in per],
+                              condition_mask=tb["condition_mask"].clone(),
+                              autoregressive_cond=ar.clone()))
         chans = [lidar_utils.convert_depth(ar[:, 0:1])]
         if auto_uses_reflectance:
             chans.append(ar[:, 1:2])
-        tb["autoregressive_cond"] = lidar_utils.normalize(torch.cat(chans, dim=1)).contiguous()
+        arc = lidar_utils.normalize(torch.cat(chans, dim=1))
+        if tuple(arc.shape[-2:]) != (H, W):
+            arc = torch.nn.functional.interpolate(arc, size=(H, W), mode="nearest-exact")
+        tb["autoregressive_cond"] = arc.contiguous()
         x = auto_ddpm.sample(tb, B, num_steps, progress=progress, rng=rng, mode=mode).clamp(-1, 1)
         frame = lidar_utils.postprocess(x)
         frames.append(frame)

@@ -342,6 +342,167 @@ def sec_c4():
     save("c4_64x2048", **out)
 
 
+def sec_c4_full():
+    """Config C4 at FULL WIDTH (round 3): `nuscenes-auto-reg-v2` (model_channels=64, 11 condition
+    channels, `autoregressive_cond`) at 64x2048 (`image_size=64`, `feature_map_size=[64,2048]`:
+    attention over 8192 / 2048 image tokens + 13 layout keys), B=1, one forward through the
+    reference's LayoutUnetV1 + layout encoder (~1.5 TFLOP on the CPU).  Columns ::4 stored."""
+    m, enc = _build_cond((64, 2048), 64, 64, cond_out=11)
+    batch = synth_layout_batch(1, 64, 2048, seed=91, n_extra=1)
+    x = seeded_randn(1, 2, 64, 2048, seed=92)
+    lam = torch.tensor([-0.25])
+    with torch.no_grad():
+        cond = enc(batch)
+        y = m(x, {"time_condition": lam, "other_condition": cond})
+    save("c4_full", y_s4=_strided(y), y_norm=y.flatten(1).norm(dim=1),
+         nparams=sum(p.numel() for p in m.parameters()))
+
+
+def _ref_lidar_utils(res, coords):
+    lidar = R.ref("utils.lidar")
+    return lidar.LiDARUtility(resolution=res, depth_format="log_depth", min_depth=1.45, max_depth=80.0,
+                              ray_angles=coords)
+
+
+def _ref_preprocess_condition_mask(lu, condition_mask, num_classes=9):
+    """tools/evaluation/sample_and_save_cond.py:106-117 (a closure of the caller script: restated,
+    every op is the reference's own LiDARUtility / torch)."""
+    import torch.nn.functional as F
+    one_hot = F.one_hot(condition_mask[:, 0, ...].long(), num_classes=num_classes).permute(0, 3, 1, 2)
+    depth = lu.convert_depth(condition_mask[:, 1, ...].unsqueeze(1))
+    return torch.cat([one_hot.float(), depth], dim=1)
+
+
+def _ref_postprocess(lu, sample):
+    """tools/evaluation/sample_and_save_cond.py:119-124."""
+    sample = lu.denormalize(sample)
+    depth, rflct = sample[:, [0]], sample[:, [1]]
+    depth = lu.revert_depth(depth)
+    return torch.cat([depth, lu.to_xyz(depth), rflct], dim=1)
+
+
+def _scene(seed, K_):
+    from lidarcrafter_amd.testing import synth_scene_boxes
+    names_all = ('car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'motorcycle', 'bicycle', 'pedestrian')
+    sb = synth_scene_boxes(K_, seed=seed)
+    names = ["ego"] + [names_all[int(c) - 1] for c in sb[:, 7]]
+    gt_boxes = np.concatenate([np.zeros((1, 7)), sb[:, :7].astype(np.float64)])
+    return gt_boxes, names
+
+
+def sec_c5_flow():
+    """Config C5 COMPOSED on the reference (round 3): user boxes -> object-branch item
+    (pipe_related.conduct_obj_data_dict :200-202 -> CustomNuscObjectDataset) -> the object sampler
+    flow of tools/vis_tools/functions/object_sampler.py:23-45 (collate, squeeze, 4-step 'ddpm' run
+    of CondContinuousLayoutGaussianDiffusion1D, NuscDataset.unscaled_objs_3d) -> background:
+    pipe_related.get_mask_cond_single :220-227 -> collate -> preprocess_condition_mask -> 4-step
+    DDIM run of the full-width box-layout-v6 denoiser -> postprocess; merged cloud = [background
+    rows outside the condition mask | object rows]; lidargen/metrics/bev.py histograms, JSD / MMD
+    against a set of seeded sweeps.  Two scenes, batch 2."""
+    import importlib
+    import importlib.util
+    from lidarcrafter_amd.testing import synth_text_features
+
+    _import_pipe_related()
+    cd = _import_custom_dataset()
+    cd.CustomNuscObjectDataset.scene_graph_assigner = None
+    sys.modules.pop("ref_vis_utils.pipe_related", None)
+    pr = importlib.import_module("ref_vis_utils.pipe_related")
+    spec = importlib.util.spec_from_file_location("ref_bev", R.REF + "/lidargen/metrics/bev.py")
+    bev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bev)
+    df = R.ref("models.diffusion")
+    pu = R.ref("models.unets.point_unet")
+    oe = R.ref("models.unets.encoders.object_gen_encoder")
+    d1 = R.ref("models.diffusion.continuous_time_1d_cond")
+
+    om = seeded_fill(pu.PointUNet(point_dim=4, cond_dims=768), salt=300).eval()
+    oenc = seeded_fill(oe.ObjectGenEncoder(num_class=8), salt=301).eval()
+    oenc.obj_text_feat = synth_text_features()
+    oenc.prepare_called = True
+    oddpm = d1.CondContinuousLayoutGaussianDiffusion1D(om, oenc, clip_sample=False).eval()
+    m, enc = _build_cond((32, 1024), 32, 64)
+    ddpm = df.CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval()
+    lu = _ref_lidar_utils((32, 1024), m.coords)
+
+    out, items, hists = {}, [], []
+    scenes = [_scene(70, 4), _scene(71, 5)]
+    obj_rows = []
+    for s_, (gt_boxes, names) in enumerate(scenes):
+        t = f"s{s_}_"
+        custom = pr.conduct_obj_data_dict([dict(gt_boxes=gt_boxes.copy(), gt_names=list(names))])
+        out[t + "fg_encoding_box"], out[t + "fg_class"] = custom["fg_encoding_box"], custom["fg_class"]
+        ods = cd.CustomNuscObjectDataset(custom_box_infos=[custom])
+        batch = ods.collate_fn([dict(custom)])
+        batch["fg_encoding_box"] = batch["fg_encoding_box"].squeeze(0)
+        batch["fg_class"] = batch["fg_class"].squeeze(0)
+        n = batch["fg_encoding_box"].shape[0]
+        rng = [torch.Generator().manual_seed(700 + 10 * s_ + i) for i in range(n)]
+        gen = oddpm.sample(batch_dict=batch, batch_size=n, num_steps=4, mode="ddpm", return_all=False,
+                           rng=rng, progress=False)
+        out[t + "gen"] = gen
+        rows = ods.unscaled_objs_3d(0, custom, gen.detach().cpu().numpy().copy())
+        out[t + "obj_rows"] = rows
+        obj_rows.append(rows)
+        items.append(pr.get_mask_cond_single([dict(gt_boxes=gt_boxes.copy(), gt_names=list(names))]))
+    ds = cd.CustomDataset(custom_box_infos=[])
+    batch = ds.collate_fn(items)
+    out["condition_mask_class"] = batch["condition_mask"][:, 0].numpy().astype(np.uint8)
+    out["condition_mask_depth"] = batch["condition_mask"][:, 1]
+    batch["concat_cond"] = _ref_preprocess_condition_mask(lu, batch["condition_mask"])
+    rng = [torch.Generator().manual_seed(800 + i) for i in range(2)]
+    x = ddpm.sample(batch_dict=batch, batch_size=2, num_steps=4, mode="ddim", rng=rng, progress=False).clamp(-1, 1)
+    frames = _ref_postprocess(lu, x)
+    out["x_s4"], out["x_norm"] = _strided(x), x.flatten(1).norm(dim=1)
+    out["frames_s4"] = _strided(frames)
+    for b in range(2):
+        fr = frames[b].numpy()
+        keep = ~(batch["condition_mask"][b, 0].numpy() > 0)[None]
+        xyz, inten = fr[1:4] * keep, fr[4:5] * keep
+        bg = np.stack([xyz[0], xyz[1], xyz[2], inten[0]], axis=-1).reshape(-1, 4)
+        bg = bg[np.linalg.norm(bg[:, :3], axis=1) > 1e-2]
+        merged = np.concatenate([bg, obj_rows[b][:, :4].astype(np.float32)], axis=0)
+        out[f"s{b}_n_bg"] = np.array([bg.shape[0]])
+        hists.append(bev.point_cloud_to_histogram(torch.from_numpy(merged[:, :3].copy())))
+    set_a = torch.stack(hists)
+    set_b = torch.stack([bev.point_cloud_to_histogram(torch.from_numpy(synth_points(30000, seed=900 + i)[:, :3]))
+                         for i in range(3)])
+    out["hist_a"] = set_a.numpy().astype(np.uint16)
+    out["jsd"], out["mmd"] = np.float64(bev.compute_jsd_2d(set_a, set_b)), np.float64(bev.compute_mmd_2d(set_a, set_b))
+    save("c5_flow", **out)
+
+
+def sec_c4_seq():
+    """Config C4 as a SEQUENCE on the reference (round 3): frame 0 of
+    tools/evaluation/sample_and_save_temporal.py:198-262 at 64x2048 with the FULL-WIDTH
+    box-layout-v6 architecture (image_size 64, feature_map_size [64,2048]): the reference's own
+    CustomDataset item at resolution (64, 2048) -> collate -> preprocess_condition_mask -> 2-step
+    'ddpm' run of CondContinuousTimeGaussianDiffusion under per-sample CPU generators ->
+    clamp -> postprocess.  B=1.  (Frames 1-4 of the device loop are checked in the GPU test by
+    feeding each HIP frame to the oracle glue, which is pinned bit-exactly on the reference.)"""
+    _import_pipe_related()
+    cd = _import_custom_dataset()
+    df = R.ref("models.diffusion")
+    m, enc = _build_cond((64, 2048), 64, 64)
+    ddpm = df.CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval()
+    lu = _ref_lidar_utils((64, 2048), m.coords)
+    gt_boxes, names = _scene(72, 5)
+    cfg = cd.DataConfig(resolution=(64, 2048))
+    ds = cd.CustomDataset([dict(gt_boxes=gt_boxes.copy(), gt_names=list(names))], cfg=cfg)
+    batch = ds.collate_fn([ds[0]])
+    out = {"condition_mask_class": batch["condition_mask"][:, 0].numpy().astype(np.uint8),
+           "condition_mask_depth_s4": _strided(batch["condition_mask"][:, 1])}
+    batch["concat_cond"] = _ref_preprocess_condition_mask(lu, batch["condition_mask"])
+    rng = [torch.Generator().manual_seed(810)]
+    xs = ddpm.sample(batch_dict=batch, batch_size=1, num_steps=2, mode="ddpm", rng=rng, progress=False,
+                     return_all=True)
+    x = xs[-1].clamp(-1, 1)
+    out["x1_s16"], out["x1_norm"] = _strided(xs[1], 16), xs[1].flatten(1).norm(dim=1)
+    out["x_s4"], out["x_norm"] = _strided(x), x.flatten(1).norm(dim=1)
+    out["frame_s8"] = _strided(_ref_postprocess(lu, x), 8)
+    save("c4_seq", **out)
+
+
 def sec_rng_state():
     """Generator state after `sample()` (base.py:73-96, continuous_time.py:226-231: DDIM eta=0 still
     draws randn_like every step): 4 numbers drawn from each per-sample generator AFTER a 3-step

@@ -1,0 +1,224 @@
+"""Configs C4 and C5 of BASELINE.json run AS CONFIGS on the HIP path:
+  * C4: the layout-conditioned denoiser at 64x2048 at FULL WIDTH (one forward of the
+    nuscenes-auto-reg-v2 architecture vs the reference, tests/golden/c4_full.npz) and the 5-frame
+    autoregressive sequence loop of tools/evaluation/sample_and_save_temporal.py:198-331 at
+    64x2048 with full-width models: frame 0 vs the reference's own run (c4_seq.npz), frames 1-4 by
+    feeding every HIP frame to the oracle glue (pinned bit-exactly on the reference's
+    pipe_related.py / CustomDataset, tests/golden/pipe{,_next}.npz) and demanding bit-equal
+    condition images and point sets back;
+  * C5: object branch -> unscaled_objs_3d -> background denoiser -> merged cloud -> BEV JSD / MMD in
+    ONE flow vs the same flow run on the reference (c5_flow.npz), every hand-over also checked by
+    feeding the HIP intermediate to the oracle.
+`pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from lidarcrafter_amd.testing import (rel_l2, seeded_fill, seeded_randn, synth_layout_batch, synth_points,
+                                      synth_scene_boxes, synth_temporal_inputs, synth_text_features)
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+NAMES = ("car", "truck", "construction_vehicle", "bus", "trailer", "motorcycle", "bicycle", "pedestrian")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def s4(x, step=4):
+    return x[..., ::step].contiguous().cpu()
+
+
+def _scene(seed, K_):
+    sb = synth_scene_boxes(K_, seed=seed)
+    names = ["ego"] + [NAMES[int(c) - 1] for c in sb[:, 7]]
+    return np.concatenate([np.zeros((1, 7)), sb[:, :7].astype(np.float64)]), names
+
+
+def test_c4_full_width_forward_golden(dev, golden):
+    """nuscenes-auto-reg-v2 architecture (model_channels 64, 11 condition channels) at 64x2048,
+    B=1: one forward vs the reference's LayoutUnetV1 + layout encoder."""
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    g = golden("c4_full")
+    m, enc = build_cond_pair((64, 2048), 64, 64, cond_out=11)
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"])
+    m, enc = m.to(dev), enc.to(dev)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(1, 64, 2048, seed=91, n_extra=1).items()}
+    x = seeded_randn(1, 2, 64, 2048, seed=92).to(dev)
+    with torch.no_grad():
+        cond = enc(batch)
+        y = m(x, {"time_condition": torch.tensor([-0.25], device=dev), "other_condition": cond})
+    r = rel_l2(s4(y), T(g["y_s4"]))
+    assert r < 2e-5, r
+    assert torch.allclose(y.flatten(1).norm(dim=1).cpu(), T(g["y_norm"]), rtol=1e-4)
+
+
+def test_c4_sequence_64x2048(dev, golden):
+    """The C4 loop: 5 frames at 64x2048, full-width box-layout-v6 (frame 0) and auto-reg-v2
+    (frames 1-4) architectures, 2 DDPM steps per frame, B=1."""
+    import lidargen  # noqa: F401
+    from lidargen.dataset.custom_dataset import CustomDataset, DataConfig
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from lidargen.utils import temporal as TG
+    from lidargen.utils.lidar import LiDARUtility
+    from oracle import temporal as OT
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    g = golden("c4_seq")
+    H, W = 64, 2048
+    m0, e0 = build_cond_pair((H, W), 64, 64, cond_out=10)
+    m1, e1 = build_cond_pair((H, W), 64, 64, cond_out=11)
+    ddpm = CondContinuousTimeGaussianDiffusion(m0, e0, cond_mode="concat").eval().to(dev)
+    auto = CondContinuousTimeGaussianDiffusion(m1, e1, cond_mode="concat").eval().to(dev)
+    lu = LiDARUtility(resolution=(H, W), depth_format="log_depth", min_depth=1.45, max_depth=80.0,
+                      ray_angles=m0.coords).to(dev)
+
+    class Cfg(DataConfig):
+        resolution = (H, W)
+
+    gt_boxes, names = _scene(72, 5)
+    ds = CustomDataset([dict(gt_boxes=gt_boxes.copy(), gt_names=list(names))], cfg=Cfg())
+    batch = ds.collate_fn([ds[0]])
+    assert np.array_equal(batch["condition_mask"][:, 0].cpu().numpy().astype(np.uint8), g["condition_mask_class"])
+    assert np.array_equal(s4(batch["condition_mask"][:, 1]).numpy(), g["condition_mask_depth_s4"])
+    batch["gt_fut_trajs"] = [synth_temporal_inputs(55, K=5)[0]]
+
+    # ---- frame 0 against the reference's own sampler run --------------------------------------
+    cond_batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    cond_batch["concat_cond"] = lu.preprocess_condition_mask(cond_batch["condition_mask"], 9)
+    xs = ddpm.sample(cond_batch, 1, 2, progress=False, rng=[torch.Generator().manual_seed(810)],
+                     mode="ddpm", return_all=True)
+    assert rel_l2(s4(xs[1], 16), T(g["x1_s16"])) < 1e-3
+    x = xs[-1].clamp(-1, 1)
+    r = rel_l2(s4(x), T(g["x_s4"]))
+    assert r < 1e-3, r
+    assert torch.allclose(x.flatten(1).norm(dim=1).cpu(), T(g["x_norm"]), rtol=1e-3)
+    assert rel_l2(s4(lu.postprocess(x), 8), T(g["frame_s8"])) < 1e-3
+
+    # ---- the 5-frame loop; every hand-over re-derived by the oracle glue from the HIP frame ----
+    trace = []
+    frames, points = TG.generate_sequence(ddpm, auto, lu, dict(batch), num_frames=5, num_steps=2, mode="ddpm",
+                                          traj_length=6, rng=[torch.Generator().manual_seed(810)],
+                                          data_cfg=Cfg(), trace=trace)
+    assert len(frames) == 5 and all(f.shape == (1, 5, H, W) for f in frames) and len(trace) == 4
+    assert all(torch.isfinite(f).all() for f in frames)
+    assert rel_l2(s4(frames[0], 8), T(g["frame_s8"])) < 1e-3          # same generator -> same frame 0
+    f0 = frames[0][0].cpu().numpy()
+    a = np.insert(np.asarray(batch["gt_fut_trajs"][0]), 0, 0, axis=1)
+    acc = OT.interp_trajs_numpy(np.cumsum(a, axis=1), M=6)
+    first = dict(gt_fut_trajs=acc[:, 1:] - acc[:, :-1], xyz=f0[1:4], reflectance=f0[4:5],
+                 gt_boxes=gt_boxes, gt_names=names, condition_mask=batch["condition_mask"][0].cpu().numpy())
+    _, rfut_bg, _, rfut_boxes, rTs, robj_pts, robj_int = OT.get_temporal_boxes_3d(first, f32=True)
+    cur = np.stack([f0[1], f0[2], f0[3], f0[4]], -1).reshape(-1, 4)
+    for t, tr in enumerate(trace):
+        assert np.array_equal(tr["cur_bg"][0].cpu().numpy(), cur), t
+        # <= 13 boxes x 6 steps of float64 host trigonometry: the loop's own scalars (equal to the
+        # oracle's to the last few bits) are what the oracle point-set functions are fed
+        fb, Tt = np.asarray(tr["gt_boxes"][0])[1:, :7], np.asarray(tr["Ts"][0])
+        assert np.allclose(fb, rfut_boxes[:, t], rtol=0, atol=1e-11) and np.allclose(Tt, rTs[t], rtol=0, atol=1e-11)
+        nxt = OT.get_next_frame_points(cur, robj_pts, robj_int, fb, names, Tt, f32=True)
+        assert tr["next_points"][0].dtype == torch.float64
+        assert np.array_equal(tr["next_points"][0].cpu().numpy(), nxt), t
+        gb = np.concatenate([np.zeros((1, 7), np.float32), fb], axis=0)
+        item = OT.custom_item(nxt, gb, names, H, W, task="autoregressive_generation")
+        assert np.array_equal(tr["autoregressive_cond"][0].cpu().numpy(), item["autoregressive_cond"]), t
+        assert np.array_equal(tr["condition_mask"][0].cpu().numpy(), item["condition_mask"]), t
+        assert (item["autoregressive_cond"][0] > 0).sum() > 1000      # the condition is not empty
+        ft = frames[t + 1][0].cpu().numpy()
+        gen = np.stack([ft[1], ft[2], ft[3], ft[4]], -1).reshape(-1, 4)
+        cur = OT.delete_fg_points(np.concatenate([rfut_bg[t], gen], axis=0), fb)
+    assert not torch.equal(frames[1], frames[2])
+
+
+def test_c5_composed_flow_golden(dev, golden):
+    """Object branch -> unscaled_objs_3d -> background denoiser -> merged cloud -> BEV histograms
+    -> JSD / MMD as ONE flow, against the same flow run on the reference (c5_flow.npz)."""
+    import lidargen  # noqa: F401
+    from lidargen.dataset.custom_dataset import CustomDataset, CustomNuscObjectDataset
+    from lidargen.metrics import bev
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from lidargen.utils import inference
+    from lidargen.utils import temporal as TG
+    from lidargen.utils.configs import __all__ as C
+    from lidargen.utils.lidar import LiDARUtility
+    from lidarcrafter_amd import ops as K
+    from oracle import metrics as OM
+    from oracle import objects as OO
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    g = golden("c5_flow")
+    oddpm, omodel = inference.load_model_object_duffusion_training(C["nuscenes-object"]())
+    seeded_fill(omodel, salt=300), seeded_fill(oddpm.condition_model, salt=301)
+    oddpm = oddpm.eval().to(dev)
+    oddpm.condition_model.set_text_features(synth_text_features(), dev)
+    m, enc = build_cond_pair((32, 1024), 32, 64)
+    ddpm = CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval().to(dev)
+    lu = LiDARUtility(resolution=(32, 1024), depth_format="log_depth", min_depth=1.45, max_depth=80.0,
+                      ray_angles=m.coords).to(dev)
+
+    scenes = [_scene(70, 4), _scene(71, 5)]
+    items, obj_rows = [], []
+    for s_, (gt_boxes, names) in enumerate(scenes):
+        t = f"s{s_}_"
+        # -- hand-over 1: user boxes -> the object branch's condition item
+        custom = TG.conduct_obj_data_dict([dict(gt_boxes=gt_boxes.copy(), gt_names=list(names))])
+        assert np.allclose(custom["fg_encoding_box"], g[t + "fg_encoding_box"], rtol=0, atol=1e-6)
+        assert np.array_equal(custom["fg_class"], g[t + "fg_class"])
+        ods = CustomNuscObjectDataset(custom_box_infos=[custom])
+        batch = ods.collate_fn([dict(custom)])
+        batch["fg_encoding_box"] = batch["fg_encoding_box"].squeeze(0).to(dev)
+        batch["fg_class"] = batch["fg_class"].squeeze(0).to(dev)
+        n = batch["fg_encoding_box"].shape[0]
+        # -- hand-over 2: the object sampler (object_sampler.py:36-43)
+        rng = [torch.Generator().manual_seed(700 + 10 * s_ + i) for i in range(n)]
+        gen = oddpm.sample(batch_dict=batch, batch_size=n, num_steps=4, mode="ddpm", return_all=False,
+                           rng=rng, progress=False)
+        r = rel_l2(gen, T(g[t + "gen"]))
+        assert r < 1e-3, (s_, r)
+        # -- hand-over 3: unit-box objects -> scene rows; the HIP objects through the oracle, and
+        #    the reference's objects through the device op against the reference's rows
+        rows = ods.unscaled_objs_3d(0, custom, gen.clone())
+        ref_rows = OO.unscaled_objs_3d(gt_boxes[1:], gen.cpu().numpy().astype(np.float64))
+        assert np.abs(rows.cpu().numpy() - ref_rows).max() < 2e-5 * max(1.0, np.abs(ref_rows).max())
+        rows_g = ods.unscaled_objs_3d(0, custom, g[t + "gen"].copy())
+        assert np.abs(rows_g - g[t + "obj_rows"]).max() < 2e-5 * max(1.0, np.abs(g[t + "obj_rows"]).max())
+        obj_rows.append(rows)
+        items.append(TG.get_mask_cond_single([dict(gt_boxes=gt_boxes.copy(), gt_names=list(names))]))
+    # -- hand-over 4: the background denoiser's condition
+    batch = CustomDataset(custom_box_infos=[]).collate_fn(items)
+    assert np.array_equal(batch["condition_mask"][:, 0].cpu().numpy().astype(np.uint8), g["condition_mask_class"])
+    assert np.array_equal(batch["condition_mask"][:, 1].cpu().numpy(), g["condition_mask_depth"])
+    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    batch["concat_cond"] = lu.preprocess_condition_mask(batch["condition_mask"], 9)
+    # -- hand-over 5: the background sampler + post-processing
+    rng = [torch.Generator().manual_seed(800 + i) for i in range(2)]
+    x = ddpm.sample(batch_dict=batch, batch_size=2, num_steps=4, mode="ddim", rng=rng, progress=False).clamp(-1, 1)
+    r = rel_l2(s4(x), T(g["x_s4"]))
+    assert r < 1e-3, r
+    frames = lu.postprocess(x)
+    assert rel_l2(s4(frames), T(g["frames_s4"])) < 1e-3
+    # -- hand-over 6: merged cloud -> BEV histogram; the HIP cloud through the oracle: bit-exact
+    hists = []
+    for b in range(2):
+        bg = TG._background_points(frames[b, 1:4].contiguous(), frames[b, 4].contiguous(),
+                                   batch["condition_mask"][b], refl_scale=1.0)
+        assert abs(bg.shape[0] - int(g[f"s{b}_n_bg"][0])) <= 8
+        merged = torch.cat([bg, obj_rows[b][:, :4]], dim=0).contiguous()
+        h = bev.point_cloud_to_histogram(merged[:, :3].contiguous())
+        assert np.array_equal(h.cpu().numpy(), OM.point_cloud_to_histogram(merged[:, :3].cpu().numpy()))
+        ref_h = g["hist_a"][b].astype(np.float64)
+        assert np.abs(h.cpu().numpy() - ref_h).sum() <= 0.01 * ref_h.sum()     # points crossing bin edges
+        hists.append(h)
+    set_a = torch.stack(hists)
+    set_b = torch.stack([bev.point_cloud_to_histogram(T(synth_points(30000, seed=900 + i)[:, :3].copy()).to(dev))
+                         for i in range(3)])
+    # -- hand-over 7: the metrics
+    jsd, mmd = float(bev.compute_jsd_2d(set_a, set_b)), float(bev.compute_mmd_2d(set_a, set_b))
+    assert abs(jsd - float(g["jsd"])) <= 2e-3 * float(g["jsd"]), (jsd, float(g["jsd"]))
+    assert abs(mmd - float(g["mmd"])) <= 2e-2 * abs(float(g["mmd"])) + 1e-9, (mmd, float(g["mmd"]))
+    oj = OM.compute_jsd_2d(set_a.cpu().numpy().astype(np.float64), set_b.cpu().numpy().astype(np.float64))
+    assert abs(jsd - oj) <= 1e-6 * max(1.0, abs(oj))
