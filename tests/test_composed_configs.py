@@ -32,6 +32,25 @@ def s4(x, step=4):
     return x[..., ::step].contiguous().cpu()
 
 
+def frames_close(frames, ref_frames, x_ref, tol=1e-3):
+    """Post-processed frames [B,5,H,W] (depth, xyz, reflectance) vs the reference's, away from the
+    SATURATED pixels.  Where the clamped sample is exactly +1 the metric depth is
+    exp2(float32(log2 81)) - 1: the correctly rounded float32 value is 80.0 (= max_depth -> the
+    pixel is masked out, what the HIP kernel returns), but torch's CPU exp2 returns 80.99999 on its
+    large-tensor path and 81.0 on its small-tensor path (checked in the build container), i.e. the
+    reference itself keeps or drops those 80 m returns depending on the tensor size / platform.
+    Compared: pixels whose reference depth lies strictly inside the (min_depth, max_depth) mask
+    window (a 1e-7 difference of the sample next to a mask threshold flips 80 m <-> 0); the pixels
+    on which the two masks disagree must be a small fraction of the unsaturated ones."""
+    d_ref, d = ref_frames[:, 0:1], frames[:, 0:1]
+    inside = ((d_ref > 1.46) & (d_ref < 79.9)).expand_as(ref_frames)
+    assert inside.float().mean() > 0.01          # random-init weights: most pixels saturate at +-1
+    unsat = x_ref[:, 0:1] < 0.9999
+    flips = (((d_ref > 0) != (d > 0)) & unsat).float().sum() / unsat.float().sum()
+    assert flips < 2e-3, float(flips)
+    return rel_l2(frames[inside], ref_frames[inside]) < tol
+
+
 def _scene(seed, K_):
     sb = synth_scene_boxes(K_, seed=seed)
     names = ["ego"] + [NAMES[int(c) - 1] for c in sb[:, 7]]
@@ -97,7 +116,8 @@ def test_c4_sequence_64x2048(dev, golden):
     r = rel_l2(s4(x), T(g["x_s4"]))
     assert r < 1e-3, r
     assert torch.allclose(x.flatten(1).norm(dim=1).cpu(), T(g["x_norm"]), rtol=1e-3)
-    assert rel_l2(s4(lu.postprocess(x), 8), T(g["frame_s8"])) < 1e-3
+    xr8 = T(g["x_s4"])[..., ::2]
+    assert frames_close(s4(lu.postprocess(x), 8), T(g["frame_s8"]), xr8)
 
     # ---- the 5-frame loop; every hand-over re-derived by the oracle glue from the HIP frame ----
     trace = []
@@ -106,7 +126,7 @@ def test_c4_sequence_64x2048(dev, golden):
                                           data_cfg=Cfg(), trace=trace)
     assert len(frames) == 5 and all(f.shape == (1, 5, H, W) for f in frames) and len(trace) == 4
     assert all(torch.isfinite(f).all() for f in frames)
-    assert rel_l2(s4(frames[0], 8), T(g["frame_s8"])) < 1e-3          # same generator -> same frame 0
+    assert frames_close(s4(frames[0], 8), T(g["frame_s8"]), xr8)         # same generator -> same frame 0
     f0 = frames[0][0].cpu().numpy()
     a = np.insert(np.asarray(batch["gt_fut_trajs"][0]), 0, 0, axis=1)
     acc = OT.interp_trajs_numpy(np.cumsum(a, axis=1), M=6)
@@ -200,13 +220,15 @@ def test_c5_composed_flow_golden(dev, golden):
     r = rel_l2(s4(x), T(g["x_s4"]))
     assert r < 1e-3, r
     frames = lu.postprocess(x)
-    assert rel_l2(s4(frames), T(g["frames_s4"])) < 1e-3
+    assert frames_close(s4(frames), T(g["frames_s4"]), T(g["x_s4"]))
     # -- hand-over 6: merged cloud -> BEV histogram; the HIP cloud through the oracle: bit-exact
     hists = []
     for b in range(2):
         bg = TG._background_points(frames[b, 1:4].contiguous(), frames[b, 4].contiguous(),
                                    batch["condition_mask"][b], refl_scale=1.0)
-        assert abs(bg.shape[0] - int(g[f"s{b}_n_bg"][0])) <= 8
+        # (the reference kept the saturated 80 m pixels outside the boxes, see frames_close)
+        n_sat = int(((x[b, 0] >= 1.0) & ~(batch["condition_mask"][b, 0] > 0)).sum())
+        assert abs(bg.shape[0] + n_sat - int(g[f"s{b}_n_bg"][0])) <= 8
         merged = torch.cat([bg, obj_rows[b][:, :4]], dim=0).contiguous()
         h = bev.point_cloud_to_histogram(merged[:, :3].contiguous())
         assert np.array_equal(h.cpu().numpy(), OM.point_cloud_to_histogram(merged[:, :3].cpu().numpy()))

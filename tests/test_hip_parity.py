@@ -903,6 +903,7 @@ def test_next_frame_points_vs_reference_golden(dev, golden):
     reference's float32 library matmuls vs correctly rounded values) agree to two float32 ulps."""
     import lidargen  # noqa: F401
     from lidargen.utils import temporal as T
+    from lidarcrafter_amd import ops as K
     from oracle import temporal as OT
 
     g = golden("pipe_next")
