@@ -1,7 +1,8 @@
 """Run a few layout-conditioned DDIM steps (nuscenes-box-layout-v6, C3 shape) -- for rocprofv3."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lidarcrafter_amd.testing import seeded_fill, synth_layout_batch
 from lidargen.utils import inference
 from lidargen.utils.configs import __all__ as C

@@ -39,6 +39,8 @@ namespace {
 __device__ __forceinline__ void epi_store(float* p, float v) {
 #if LC_EPI_MODE == 2
     asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+#elif LC_EPI_MODE == 3
+    asm volatile("global_store_dword %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
 #else
     *p = v;
 #endif
@@ -58,6 +60,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_EMIT_ABL
 #define LC_EMIT_ABL 0   // pre-split kernel, statistics epilogue ablation: 1 no per-element sums, 2 no reductions / stores
 #endif
+#ifndef LC_PIPE_ROWS
+#define LC_PIPE_ROWS 1  // fused-GroupNorm rows are read ahead of the tap's fragment fetch (no lgkmcnt(0) drain)
+#endif
+#ifndef LC_TIMING
+#define LC_TIMING 0     // developer build: s_memtime phase totals of the fp32-input pipelined kernel -> lc_dbg
+#endif
 #ifndef LC_PS_SCHED
 #define LC_PS_SCHED 0   // pre-split kernel: 0 = fence per tap (reads of tap t+1, then MFMAs of tap t), 1 = 1:1 interleave
 #endif
@@ -66,6 +74,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // product; 1 / 3 / 5 exist only to MEASURE what fewer passes cost in accuracy
 // (devtools/passes_error.py, profiles/r02_passes_error.json).
 #define LC_F16X2_TERMS 7
+#endif
+#if LC_TIMING
+__device__ unsigned long long lc_dbg[16];
 #endif
 constexpr float X_PRESCALE_DEFAULT = 16.0f, W_PRESCALE_DEFAULT = 256.0f;
 
@@ -681,12 +692,18 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     // A unit (8 channels of one position) is staged in four channel-pair steps spread over the taps
     // of the chunk (2 steps per tap: ~25 VALU in the shadow of 6 MFMAs), then written.
     half8 st_hi[NXU], st_lo[NXU];
-    auto stage_pair = [&](float (&xr)[NXU][8], int i, int q, int ch) {
+    auto read_row = [&](int i, int q, int ch) -> f32x4 {
+        if constexpr (GNM != 0) {
+            const f32x4* g = x_ok[i] ? ctab + ch * 8 + x_cb[i] * 4 : ctab + (a.Cgn >> 1);
+            return g[q];
+        } else {
+            return f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage_pair = [&](float (&xr)[NXU][8], int i, int q, const f32x4 row) {
         if (LC_ABLATE & 1) { asm volatile("" ::"v"(xr[i][2 * q]), "v"(xr[i][2 * q + 1])); return; }
         h2_t ph, pl;
         if constexpr (GNM != 0) {
-            const f32x4* g = x_ok[i] ? ctab + ch * 8 + x_cb[i] * 4 : ctab + (a.Cgn >> 1);
-            const f32x4 row = g[q];
             f2_t v = {xr[i][2 * q], xr[i][2 * q + 1]};
             const f2_t A = {row.x, row.y}, Bv = {row.z, row.w};
             v = __builtin_elementwise_fma(v, A, Bv);
@@ -753,6 +770,16 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int s = (LC_ABLATE & 4) ? 0 : (tap & 1);
+            // rows of the fused norm for THIS tap's staging steps: requested ahead of the fragment
+            // fetch, so that their first use waits with lgkmcnt(#fragment reads), not lgkmcnt(0)
+            // (which drained the prefetched fragments eight times per chunk; ISA of r02)
+            f32x4 rows[SPT];
+            if (LC_PIPE_ROWS && GNM != 0) {
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st)
+                    if (tap == step_tap(st)) rows[st % SPT] = read_row(st >> 2, st & 3, chn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (tap + 1 < NTAP && !(LC_ABLATE & 4)) fetch(tap + 1, s ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             // loads of this chunk's successor were issued before tap 0; consume them as late as
@@ -762,7 +789,8 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st)
                 if (tap == step_tap(st)) {
-                    stage_pair(xr, st >> 2, st & 3, chn);
+                    stage_pair(xr, st >> 2, st & 3,
+                               (LC_PIPE_ROWS && GNM != 0) ? rows[st % SPT] : read_row(st >> 2, st & 3, chn));
                     if ((st & 3) == 3) commit_x(nxt, st >> 2);
                 }
 #pragma unroll
@@ -842,7 +870,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #pragma unroll
     for (int i = 0; i < NXU; ++i) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stage_pair(xr, i, q, 0);
+        for (int q = 0; q < 4; ++q) stage_pair(xr, i, q, read_row(i, q, 0));
         commit_x(cur, i);
     }
 #pragma unroll
