@@ -60,6 +60,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_EMIT_ABL
 #define LC_EMIT_ABL 0   // pre-split kernel, statistics epilogue ablation: 1 no per-element sums, 2 no reductions / stores
 #endif
+#ifndef LC_DEF_AUX
+#define LC_DEF_AUX 16   // cache policy of the deferred epilogue's output stores: 16 = sc1 (write-through), 0 = write-back, 2 = nt
+#endif
 #ifndef LC_PIPE_ROWS
 #define LC_PIPE_ROWS 1  // fused-GroupNorm rows are read ahead of the tap's fragment fetch (no lgkmcnt(0) drain)
 #endif
@@ -541,6 +544,190 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (descriptor + per-lane voffset + uniform
+// soffset; out of range -> zeros) -> LDS at dst + 16 * lane.  (The builtin exists in the device
+// pass only; the host pass needs just the kernel's stub.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_vptr dst, unsigned voff,
+                                          unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+// s_waitcnt vmcnt(n) for a count that is a compile-time constant only after inlining
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define LC_WV(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        LC_WV(0) LC_WV(1) LC_WV(2) LC_WV(3) LC_WV(4) LC_WV(5) LC_WV(6) LC_WV(7) LC_WV(8) LC_WV(9) LC_WV(10)
+        LC_WV(11) LC_WV(12) LC_WV(13) LC_WV(14) LC_WV(15) LC_WV(16) LC_WV(17) LC_WV(18) LC_WV(19) LC_WV(20)
+        LC_WV(21) LC_WV(22) LC_WV(23) LC_WV(24) LC_WV(25) LC_WV(26) LC_WV(27) LC_WV(28) LC_WV(29) LC_WV(30)
+        LC_WV(31) LC_WV(32)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef LC_WV
+}
+
+// ---------------------------------------------------------------------------------------------
+// DEFERRED EPILOGUE (round 3).  s_memtime phase totals of the level-0 launches (devtools/
+// conv_phases.py, profiles/r03_conv_phases.txt): a wave spent 36 % of its lifetime ISSUING the 32
+// write-through stores of a tile's epilogue -- ~375 cycles per `global_store_dword`: all 256 CUs
+// reach their epilogue together and the burst (16.8 MB per tile round, + the residual reads) runs
+// at the ~3.3 TB/s the fabric takes writes at, with every matrix pipe idle.  The bytes have to be
+// written; what can change is WHEN.  A finished tile's raw accumulators are therefore parked in a
+// second register set and finalised -- x out_unscale, + residual, x out_scale, GroupNorm statistics,
+// one store -- VPT values per tap inside the MFMA stream of the NEXT tile's first DCH chunks, so
+// the write traffic of tile t runs under the MFMAs of tile t+1; only the last tile of a block
+// drains in the open.  The residual is fetched just in time (LAG slots ahead of its use, RING
+// registers instead of a 32-register tile), the bias enters through the accumulator's initial
+// value (bias / out_unscale: the scale is a power of two, exact) -- both were needed to make room
+// for the parked accumulators at 256 registers per wave.
+// Loads and stores are raw buffer operations on descriptors of sample b (residual: num_records 0
+// when there is none -> zeros): out-of-image pixels, ragged channel tails and "no previous tile"
+// are an out-of-range offset, so the per-value code has no branch and stays in the MFMAs' basic
+// block.
+template <class C, bool EMIT>
+struct DefEpi {
+    static constexpr int TCO = C::TCO_, TPX = C::TPX_, NTAP = C::NTAP;
+    static constexpr int NV = TCO * TPX * 16;              // values per thread and tile
+    static constexpr int DCH = 4;                          // chunks of the next tile carrying deferred work
+    static constexpr int NSLOT = DCH * NTAP;
+    static constexpr int VPT = (NV + NSLOT - 1) / NSLOT;   // values per tap slot
+    static constexpr int NUSED = (NV + VPT - 1) / VPT;     // slots that carry values
+    static constexpr int LAG = 3, RING = (LAG + 1) * VPT;
+    static constexpr unsigned OOB = 0x80000000u;
+    // Value order: k = ((i * 4 + m) * TPX + j) * 4 + q  <->  accumulator (i, j, r = 4 m + q): the 4 * TPX
+    // values of one channel OCTET (m; registers 4m .. 4m+3 of both lane halves) are consecutive, so
+    // only one statistics triple is alive at a time and each octet's reduction + entry store follows
+    // its last value (12 DPP adds every 4 * TPX values instead of 96 at the end of the tile).
+    static constexpr int OCTV = 4 * TPX;
+
+    f32x16 accp[TCO][TPX];
+    float rq[RING];
+    float st_p, st_s, st_q;    // the running octet: pivot, sum (v - p), sum (v - p)^2
+    unsigned voff[TPX];        // byte offset of (channel co_wave, pixel j) in the sample; OOB = nothing to do
+    __amdgpu_buffer_rsrc_t rs_y, rs_r, rs_o;
+    float out_unscale, out_scale;
+    unsigned HW4;              // bytes per channel plane
+    int co_wave, Co;
+    float nv8;                 // 8 x valid pixels of the parked tile (entry field)
+    unsigned ent_off;          // byte offset of the parked tile's entry of octet 0 of this wave (lane 63), or OOB
+    unsigned oct_stride;       // bytes between the entries of consecutive octets
+
+    __device__ __forceinline__ void init(float* yb, const float* rb, int Co_, int HW, float unscale,
+                                         float oscale, int co_wave_, f32x4* ostats_b, int oslots) {
+        const unsigned bytes = (unsigned)Co_ * (unsigned)HW * 4u;
+        rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, bytes, 0x00020000);
+        rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rb, 0, rb ? bytes : 0u, 0x00020000);
+        rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)ostats_b, 0,
+                                                 ostats_b ? (unsigned)(Co_ >> 3) * (unsigned)oslots * 16u : 0u,
+                                                 0x00020000);
+        out_unscale = unscale; out_scale = oscale; HW4 = (unsigned)HW * 4u;
+        co_wave = co_wave_; Co = Co_;
+        oct_stride = (unsigned)oslots * 16u;
+        nv8 = 0.f; ent_off = OOB;
+        st_p = st_s = st_q = 0.f;
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) voff[j] = OOB;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[i][j][r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RING; ++q) rq[q] = 0.0f;
+    }
+    static __device__ __forceinline__ int i_of(int k) { return k / (16 * TPX); }
+    static __device__ __forceinline__ int m_of(int k) { return (k / OCTV) & 3; }
+    static __device__ __forceinline__ int j_of(int k) { return (k >> 2) % TPX; }
+    static __device__ __forceinline__ int cor_of(int k) {   // channel of value k relative to co_wave
+        return i_of(k) * 32 + (k & 3) + 8 * m_of(k);
+    }
+    __device__ __forceinline__ unsigned off_of(int k) const {
+        return (co_wave + cor_of(k) < Co) ? voff[j_of(k)] : OOB;
+    }
+    __device__ __forceinline__ void issue_res(int k) {
+        rq[k % RING] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off_of(k), (unsigned)cor_of(k) * HW4, 0));
+    }
+    __device__ __forceinline__ void finalize(int k) {
+        const int i = i_of(k), m = m_of(k), j = j_of(k), r = 4 * m + (k & 3);
+        const float v = fmaf(accp[i][j][r], out_unscale, rq[k % RING]) * out_scale;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, off_of(k),
+                                              (unsigned)cor_of(k) * HW4, LC_DEF_AUX);
+        if constexpr (EMIT) {
+            const bool pok = voff[j] != OOB;
+            if (k % OCTV == 0) {
+                st_p = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
+                st_s = 0.f; st_q = 0.f;
+            }
+            const float d = pok ? v - st_p : 0.0f;
+            st_s += d;
+            st_q = fmaf(d, d, st_q);
+            if (k % OCTV == OCTV - 1) {                  // the octet is complete: one entry from lane 63
+                const float s_ = wave_sum_to_lane63(st_s);
+                const float q_ = wave_sum_to_lane63(st_q);
+                const int oct = i * 4 + m;               // octet index inside this wave's channel rows
+                const bool ok = ent_off != OOB && co_wave + i * 32 + 8 * m < Co;   // (co_wave carries 4 * kh <= 4)
+                const f32x4 e = {st_p, nv8, s_, q_};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, e),
+                                                       rs_o, ok ? ent_off : OOB, (unsigned)oct * oct_stride, 0);
+            }
+        }
+    }
+    // slot s of the deferred stream (s static after unrolling)
+    __device__ __forceinline__ void slot(int s) {
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+            if ((s + LAG) * VPT + u < NV) issue_res((s + LAG) * VPT + u);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+            if (s * VPT + u < NV) finalize(s * VPT + u);
+    }
+    // VMEM operations slot s issues (for the manual vmcnt in front of the chunk barrier)
+    static __device__ __forceinline__ int ops_of(int s) {
+        int n = 0;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            n += ((s + LAG) * VPT + u < NV) ? 1 : 0;
+            const int k = s * VPT + u;
+            n += (k < NV) ? 1 : 0;
+            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? 1 : 0;
+        }
+        return n;
+    }
+    __device__ __forceinline__ void flush_from(int s0) {
+#pragma unroll
+        for (int s = 0; s < NUSED; ++s)
+            if (s >= s0) slot(s);
+    }
+    // park the finished tile at (h0, w0): accumulators, pixel offsets, statistics entry, first residuals
+    __device__ __forceinline__ void begin(const f32x16 (&acc)[TCO][TPX], int h0, int w0, int H, int W,
+                                          int wpx, int lane, int tiles_w, int HWpx, int co_blk) {
+        const int l31 = lane & 31;
+        int nvalid = 0;
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+            const int t = wpx * TPX + j;
+            const int tr = t / C::TPR, tc = t - tr * C::TPR;
+            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+            const bool pok = gh < H && gw < W;
+            voff[j] = pok ? (unsigned)(co_wave * HWpx + gh * W + gw) * 4u : OOB;
+            if constexpr (EMIT) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) accp[i][j] = acc[i][j];
+        }
+        if constexpr (EMIT) {
+            const int slot_id = ((h0 / C::TH_) * tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
+            nv8 = (float)(8 * nvalid);
+            ent_off = lane == 63 ? (unsigned)(co_blk >> 3) * oct_stride + (unsigned)slot_id * 16u : OOB;
+        }
+#pragma unroll
+        for (int k = 0; k < LAG * VPT; ++k)
+            if (k < NV) issue_res(k);
+    }
+};
+
 // GNM: 0 = plain input, 1 = GroupNorm(+AdaGN) + SiLU of the input fused into staging, 2 = GroupNorm
 // only.  A template parameter, not a branch: the staging arithmetic must sit in the same basic block
 // as the MFMAs (as a runtime branch it formed its own block, with every LDS latency of the row
@@ -560,11 +747,22 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     constexpr int NXU = (CB * WPC + NWV - 1) / NWV;    // units per thread
     // every thread always loads NXU / NWU units (no exec-mask branches inside the K loop: a whole
     // chunk is one basic block); units past the end of a plane are stored to one dummy slot.
-    constexpr int XUP = XU + 1, WUP = WU + 1;
-    constexpr int BUF = 2 * XUP + 2 * WUP;             // half8 units per LDS buffer
+    // Weights travel global -> LDS by LDS-DMA (round 3; as in the pre-split kernel): no weight
+    // VGPRs, no ds_write, and the ~36 registers this frees are what the deferred epilogue parks a
+    // tile's accumulators in.  Each wave issues KW DMA instructions per chunk (1 KiB each, one per
+    // tap, taps 0 .. KW-1); instruction index past the end -> out of range -> zeros into a dummy block.
+    constexpr int NWI = (WU + 63) / 64, WS = NWI * 64;            // DMA instructions / units per weight plane
+    constexpr int KW = (2 * NWI + NWV - 1) / NWV;
+    static_assert(KW <= NTAP || NTAP == 1, "one weight DMA slot per tap");
+    constexpr int XUP = XU + 1;
+    constexpr int BUF = 2 * XUP + 2 * WS + 64;         // half8 units per LDS buffer (+ the dummy block)
+    constexpr unsigned OOB_W = 0x80000000u;
     __shared__ half8 lds[2 * BUF];
     __shared__ f32x4 ctab[GN_MAX_C];                   // fused input GroupNorm rows of sample b
     __shared__ float2 gtab[GN_MAX_G];                  // (mean, rstd) per group while they are derived
+    // bias / (x_unscale * w_unscale) of the block's channels: the accumulators START from it (the
+    // scale is a power of two: exact), so no bias registers are held across the K loop
+    __shared__ float bias_s[BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -634,16 +832,29 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         }
     };
     set_tile(h0, w0);
-    long long w_idx[NWU];  // unit index of this thread's weight units for chunk 0
+    // weight DMA: descriptor over both planes (the lo plane lies behind the hi plane in ONE allocation,
+    // checked by the host entry), per-lane source offsets and the LDS block of every slot
+    const unsigned wl_delta = (unsigned)((const char*)a.wl - (const char*)a.wh);
+    const unsigned wplane_b = (unsigned)(NTAP * a.Cib) * (unsigned)a.Cop * 16u;
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, wl_delta + wplane_b,
+                                                                    0x00020000);
+    unsigned voff_w[KW];
+    int loff_w[KW];
 #pragma unroll
-    for (int i = 0; i < NWU; ++i) {
-        int e = tid + i * NT;
-        if (e >= WU) e = WU - 1;                        // padding units duplicate the last one
+    for (int q = 0; q < KW; ++q) {
+        const int j = wave + q * NWV;
+        const int plane = j / NWI, e = (j - plane * NWI) * 64 + lane;
         const int row = e / BN, cu = e - row * BN;
         const int tap = row / CB, cb = row - tap * CB;
-        w_idx[i] = ((long long)tap * a.Cib + cb) * a.Cop + co0 + cu;
+        loff_w[q] = j < 2 * NWI ? 2 * XUP + plane * WS + (j - plane * NWI) * 64 : 2 * XUP + 2 * WS;
+        voff_w[q] = (j < 2 * NWI && e < WU)
+                        ? (unsigned)((tap * a.Cib + cb) * a.Cop + co0 + cu) * 16u + plane * wl_delta
+                        : OOB_W;
     }
-    const long long w_chunk = (long long)CB * a.Cop;    // unit stride between K chunks
+    const unsigned w_chunk = (unsigned)CB * (unsigned)a.Cop * 16u;   // bytes between K chunks
+    auto dma_w = [&](half8* buf, int q, int ch) {
+        if (!(LC_ABLATE & 2)) lds_dma16(rs_w, (lds_vptr)(buf + loff_w[q]), voff_w[q], (unsigned)ch * w_chunk);
+    };
 
     auto load_x = [&](float (&xr)[NXU][8], int ch) {
 #pragma unroll
@@ -654,23 +865,25 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
                     float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, x_voff[i],
                                                                 (unsigned)(ch * 16 + k) * HW * 4u, 0));
     };
-    auto load_w = [&](half8 (&wr)[2 * NWU], int ch) {
+
+    for (int i = tid; i < BN; i += NT)
+        bias_s[i] = (a.bias && co0 + i < a.Co) ? a.bias[co0 + i] * (1.0f / out_unscale) : 0.0f;
+    const int kh = lane >> 5, l31 = lane & 31;
+    f32x16 acc[C::TCO_][C::TPX_];
+    auto acc_init = [&]() {                            // (first call: behind the prologue's barriers)
 #pragma unroll
-        for (int i = 0; i < NWU; ++i) {
-            wr[2 * i] = a.wh[w_idx[i] + ch * w_chunk];
-            wr[2 * i + 1] = a.wl[w_idx[i] + ch * w_chunk];
-        }
+        for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(&bias_s[(wco * C::TCO_ + i) * 32 + 8 * m + 4 * kh]);
+#pragma unroll
+                for (int j = 0; j < C::TPX_; ++j) {
+                    acc[i][j][4 * m] = bq.x; acc[i][j][4 * m + 1] = bq.y;
+                    acc[i][j][4 * m + 2] = bq.z; acc[i][j][4 * m + 3] = bq.w;
+                }
+            }
     };
 
-    f32x16 acc[C::TCO_][C::TPX_];
-#pragma unroll
-    for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TPX_; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int kh = lane >> 5, l31 = lane & 31;
     int xbase[C::TPX_];
 #pragma unroll
     for (int j = 0; j < C::TPX_; ++j) {
@@ -680,10 +893,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     }
     const int wbase = kh * BN + wco * C::TCO_ * 32 + l31;
 
-    auto store_tap_w = [](int i) {
-        const int t = NTAP - 1 - (NWU - 1 - i) / 2;
-        return t > 0 ? t : 0;
-    };
     // fused GroupNorm rows in LDS, per channel PAIR: (A0, A1, B0, B1) with A = rstd * gamma' * xs,
     // B = (beta' - mu * A') * xs  (x_scale is a power of two: folding it here is exact), so that a
     // pair of channels costs one broadcast ds_read_b128 and one v_pk_fma_f32;  4 zero quads behind
@@ -735,21 +944,17 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         const int first = NTAP - 1 - ntaps > 0 ? NTAP - 1 - ntaps : 0;
         return first + st / SPT;
     };
-    auto store_w = [&](half8* buf, const half8 (&wr)[2 * NWU], int i) {
-        if (LC_ABLATE & 1) { asm volatile("" ::"v"(wr[2 * i]), "v"(wr[2 * i + 1])); return; }
-        const int e = tid + i * NT;
-        const int d = e < WU ? e : WU;
-        buf[2 * XUP + d] = wr[2 * i];
-        buf[2 * XUP + WUP + d] = wr[2 * i + 1];
-    };
     // one chunk of MFMAs from `cur`; the split+store of the NEXT chunk's registers into `nxt`
     // is spread over the taps (same basic block as the MFMAs)
-    auto compute = [&](const half8* cur, half8* nxt, float (&xr)[NXU][8],
-                       const half8 (&wr)[2 * NWU], int chn) {
+    typedef DefEpi<C, EMIT_STATS> DE;
+    DE de;
+    // dslot0 >= 0: the taps of this chunk also carry slots dslot0 .. dslot0 + NTAP - 1 of the parked
+    // tile's deferred epilogue (a compile-time constant at every call site)
+    auto compute = [&](const half8* cur, half8* nxt, float (&xr)[NXU][8], int chn, int dslot0) {
         const half8* cxh = cur;
         const half8* cxl = cur + XUP;
         const half8* cwh = cur + 2 * XUP;
-        const half8* cwl = cwh + WUP;
+        const half8* cwl = cwh + WS;
         // operand fragments are software pipelined ONE TAP AHEAD (two register sets, static
         // parity after unrolling): with one wave per SIMD nothing else hides the LDS latency.
         half8 ah[2][C::TCO_], al[2][C::TCO_], bh[2][C::TPX_], bl[2][C::TPX_];
@@ -782,6 +987,15 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
             }
             if (tap + 1 < NTAP && !(LC_ABLATE & 4)) fetch(tap + 1, s ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            if (dslot0 >= 0 && dslot0 + tap < DE::NUSED) de.slot(dslot0 + tap);
+            // this tap's weight DMA of chunk chn (behind the deferred slot: the wait in front of the
+            // chunk barrier then leaves exactly the later taps' deferred loads / stores in flight)
+            if (NTAP == 1) {
+#pragma unroll
+                for (int q = 0; q < KW; ++q) dma_w(nxt, q, chn);
+            } else if (tap < KW) {
+                dma_w(nxt, tap, chn);
+            }
             // loads of this chunk's successor were issued before tap 0; consume them as late as
             // possible: x units over taps [T0, T0+NXU), weight units over the last taps.
             // (A finer sched_group_barrier interleave was measured 3-10 % slower than letting
@@ -793,9 +1007,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
                                (LC_PIPE_ROWS && GNM != 0) ? rows[st % SPT] : read_row(st >> 2, st & 3, chn));
                     if ((st & 3) == 3) commit_x(nxt, st >> 2);
                 }
-#pragma unroll
-            for (int i = 0; i < NWU; ++i)
-                if (tap == store_tap_w(i)) store_w(nxt, wr, i);
             if (LC_ABLATE & 32) {   // no MFMAs: keep the fragments alive
 #pragma unroll
                 for (int i = 0; i < C::TCO_; ++i) asm volatile("" ::"v"(ah[s][i]), "v"(al[s][i]));
@@ -832,10 +1043,10 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     const int nchunk = a.Cib / CB;
     const int last = nchunk - 1;
     float xr[NXU][8];
-    half8 wr[2 * NWU];
     // prologue: chunk 0 -> cur
     load_x(xr, 0);
-    load_w(wr, 0);
+#pragma unroll
+    for (int q = 0; q < KW; ++q) dma_w(cur, q, 0);
     if constexpr (GNM != 0) {   // rows of the fused input norm, derived while the chunk-0 loads are in flight
         if (a.gs.partials) {
             for (int i = tid; i < a.Cgn; i += NT) ctab[i] = gn_row_from_stats(a.gs, xb, b, i, a.Ci, HW);
@@ -873,124 +1084,95 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         for (int q = 0; q < 4; ++q) stage_pair(xr, i, q, read_row(i, q, 0));
         commit_x(cur, i);
     }
-#pragma unroll
-    for (int i = 0; i < NWU; ++i) store_w(cur, wr, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's weight DMA has landed
     __syncthreads();
-    // epilogue operands are fetched early so that the end of the block is stores only: bias before
-    // the K loop, the residual tile while the last chunk's MFMAs run.
     const int co_wave = co0 + wco * C::TCO_ * 32 + 4 * kh;
-    float bias_r[C::TCO_][16];
-#pragma unroll
-    for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-            bias_r[i][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
-        }
-    float res_r[C::TCO_][C::TPX_][16];
-    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
-    auto prefetch_res = [&]() {
-#pragma unroll
-        for (int j = 0; j < C::TPX_; ++j) {
-            const int t = wpx * C::TPX_ + j;
-            const int tr = t / C::TPR, tc = t - tr * C::TPR;
-            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-            const bool pok = gh < H && gw < W;
-            const long long poff = (long long)gh * W + gw;
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    res_r[i][j][r] = (rb && pok && co < a.Co && !(LC_ABLATE & 16)) ? rb[(long long)co * HW + poff] : 0.0f;
-                }
-        }
-    };
-    auto k_iter = [&](int ch, int nxt_ch) {
-        // issue the loads of the next chunk (unconditional), run the MFMAs of chunk ch and store
-        // the loaded chunk into the other buffer during the last taps; one barrier.
-        if (!(LC_ABLATE & 2)) {
-            load_x(xr, nxt_ch);
-            load_w(wr, nxt_ch);
-        }
+    float* yb = a.y + (long long)b * a.y_bs;
+    const float* rb = (a.res && !(LC_ABLATE & 16)) ? a.res + (long long)b * a.res_bs : nullptr;
+    de.init(yb, rb, a.Co, HW, out_unscale, a.out_scale, co_wave,
+            a.ostats ? a.ostats + (long long)b * (a.Co >> 3) * a.oslots : nullptr, a.oslots);
+    acc_init();
+#if LC_TIMING
+    unsigned long long t_comp = 0, t_bar = 0, t_epi = 0, n_chunk = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    auto k_iter = [&](int nxt_ch, int dslot0) {
+        // issue the loads of the next chunk (unconditional), run the MFMAs of the chunk in `cur`
+        // (+ the deferred epilogue slots of the parked tile) and stage the loaded chunk into the
+        // other buffer during the last taps; one barrier.
+        if (!(LC_ABLATE & 2)) load_x(xr, nxt_ch);
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc would
                                              // otherwise sink every load next to its use)
-        compute(cur, nxt, xr, wr, nxt_ch);
-        __syncthreads();
+#if LC_TIMING
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
+        compute(cur, nxt, xr, nxt_ch, dslot0);
+#if LC_TIMING
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
+        // Chunk barrier.  NOT __syncthreads(): its workgroup release fence makes hipcc drain every
+        // pending LDS-DMA with vmcnt(0), which would also wait for the deferred epilogue's
+        // write-through stores to be acknowledged -- the latency this kernel is built to hide.
+        // Needed: this wave's ds_writes done (lgkmcnt), its weight DMAs landed = everything but the
+        // deferred loads / stores issued in the taps after the last DMA slot (VMEM returns in order).
+        {
+            int later = 0;
+#pragma unroll
+            for (int tap = (NTAP == 1 ? 1 : KW); tap < NTAP; ++tap) {
+                const int sl = dslot0 + tap;
+                if (dslot0 >= 0 && sl < DE::NUSED) later += DE::ops_of(sl);
+            }
+            wait_vmcnt(later);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if LC_TIMING
+        t_comp += tb - ta; t_bar += __builtin_amdgcn_s_memtime() - tb; ++n_chunk;
+#endif
         half8* t = cur; cur = nxt; nxt = t;
     };
-    float* yb = a.y + (long long)b * a.y_bs;
     for (int tile = 0; tile < tpb; ++tile) {
-        for (int ch = 0; ch < last; ++ch) k_iter(ch, ch + 1);
-        prefetch_res();          // the last chunk is peeled: no branch in the steady-state loop
         const bool more = tile + 1 < tpb;
-        if (more) set_tile(h0 + dh, w0 + dw);         // x offsets of the NEXT tile (uniform branch)
-        k_iter(last, more ? 0 : last);                // prefetches chunk 0 of the next tile
-        // ---- epilogue of this tile: stores only (bias / residual already in registers) --------
-        // (EMIT_STATS is a kernel template parameter, not a branch: the statistics code must not
-        //  cost the plain kernel any registers)
-        // statistics of what is stored, one accumulator pair per octet (8 channels = registers
-        // 4m..4m+3 of both lane halves), around the tile's first value of that octet
-        float st_p[C::TCO_][4], st_s[C::TCO_][4], st_q[C::TCO_][4];
-        int nvalid = 0;
+        // the chunk that is staged while chunk ch runs: ch + 1, or the first chunk of the next tile
+        // (whose x offsets are set right before; uniform branches, between two chunks)
+        auto iter = [&](int ch, int dslot0) {
+            if (ch == last && more) set_tile(h0 + dh, w0 + dw);
+            k_iter(ch == last ? (more ? 0 : last) : ch + 1, dslot0);
+        };
+        // the first DCH chunks are peeled: their taps carry the parked tile's deferred epilogue
 #pragma unroll
-        for (int j = 0; j < C::TPX_; ++j) {
-            const int t = wpx * C::TPX_ + j;
-            const int tr = t / C::TPR, tc = t - tr * C::TPR;
-            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-            const bool pok = gh < H && gw < W;
-            const long long poff = (long long)gh * W + gw;
-            if constexpr (EMIT_STATS) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if constexpr (!EMIT_STATS) {
-                        if (pok && co < a.Co) {
-                            const float v = (acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r];
-                            if (!(LC_ABLATE & 8) || v == 1.2345e-30f) epi_store(&yb[(long long)co * HW + poff], v * a.out_scale);
-                        }
-                    } else {
-                        const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
-                                        a.out_scale;
-                        if (pok && co < a.Co && (!(LC_ABLATE & 8) || v == 1.2345e-30f)) epi_store(&yb[(long long)co * HW + poff], v);
-                        const int m = r >> 2;
-                        if (j == 0 && (r & 3) == 0) {
-                            st_p[i][m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
-                            st_s[i][m] = 0.f; st_q[i][m] = 0.f;
-                        }
-                        const float d = pok ? v - st_p[i][m] : 0.0f;
-                        st_s[i][m] += d;
-                        st_q[i][m] = fmaf(d, d, st_q[i][m]);
-                    }
-                    acc[i][j][r] = 0.0f;
-                }
-            }
+        for (int c = 0; c < DE::DCH; ++c)
+            if (c < nchunk) iter(c, c * NTAP);
+        if (nchunk < DE::DCH) {                        // short K (Ci = 32): the rest of the parked tile now
+            if (nchunk == 1) de.flush_from(NTAP);
+            else if (nchunk == 2) de.flush_from(2 * NTAP);
+            else de.flush_from(3 * NTAP);
         }
-        if constexpr (EMIT_STATS) {
-            // launder the loop-invariant inputs of the entry addresses / store predicates: hipcc
-            // would otherwise hoist them above the K loop and spill them across it
-            int oslots = a.oslots, co_lim = a.Co;
-            asm volatile("" : "+s"(oslots), "+s"(co_lim));
-            const int slot = ((h0 / C::TH_) * a.tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
-            const int co_blk = co0 + wco * C::TCO_ * 32;       // first channel of this wave's rows
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int co_oct = co_blk + i * 32 + 8 * m;
-                    const float s_ = wave_sum_to_lane63(st_s[i][m]);
-                    const float q_ = wave_sum_to_lane63(st_q[i][m]);
-                    if (lane == 63 && co_oct < co_lim)
-                        a.ostats[((long long)b * (co_lim >> 3) + (co_oct >> 3)) * oslots + slot] =
-                            f32x4{st_p[i][m], (float)(8 * nvalid), s_, q_};
-                }
-            }
-        }
+        for (int ch = DE::DCH; ch < nchunk; ++ch) iter(ch, -1);
+        // park this tile; the accumulators restart from the bias
+        de.begin(acc, h0, w0, H, W, wpx, lane, a.tiles_w, HW, co0 + wco * C::TCO_ * 32);
+        acc_init();
         h0 += dh; w0 += dw;
     }
+#if LC_TIMING
+    const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
+    de.flush_from(0);                                  // the last tile drains in the open
+#if LC_TIMING
+    t_epi = __builtin_amdgcn_s_memtime() - te0;
+#endif
     publish_amax(a.range, am, amax_seen);
+#if LC_TIMING
+    if (lane == 0) {
+        atomicAdd(&lc_dbg[0], __builtin_amdgcn_s_memtime() - t_start);   // wave lifetime from the prologue's end
+        atomicAdd(&lc_dbg[2], t_comp);
+        atomicAdd(&lc_dbg[3], t_bar);
+        atomicAdd(&lc_dbg[4], t_epi);
+        atomicAdd(&lc_dbg[5], n_chunk);
+        atomicAdd(&lc_dbg[6], 1ull);
+    }
+#endif
 }
 
 
@@ -1007,16 +1189,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 // and epilogue (bias / residual / scale / GroupNorm statistics of the output) as
 // conv_f16x2_pipe_kernel.  LDS image of a plane = unit index e = (cb, row, col) exactly as there,
 // padded to whole waves (the pad lanes read out of range -> zeros).
-// one LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (descriptor + per-lane voffset + uniform
-// soffset; out of range -> zeros) -> LDS at dst + 16 * lane.  (The builtin exists in the device
-// pass only; the host pass needs just the kernel's stub.)
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_vptr dst, unsigned voff,
-                                          unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
-#endif
-}
-
 template <class C, bool EMIT_STATS>
 __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvArgsH a) {
     constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
@@ -1374,6 +1546,10 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
             return LC_EUNSUP;
         }
     }
+    {   // the weight DMA addresses the lo plane through the hi plane's descriptor: one allocation
+        const long long d = (const char*)a.wl - (const char*)a.wh;
+        if (d <= 0 || d >= (1ll << 31)) return LC_EINVAL;
+    }
     const int gnm = a.gn ? (a.gn_silu ? 1 : 2) : 0;
 #define LC_PIPE_LAUNCH(E, G) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, E, G>), grid, dim3(C::NT), 0, st, a)
     if (a.ostats) {
@@ -1662,6 +1838,15 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     }
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
 }
+
+#if LC_TIMING
+extern "C" int lc_debug_read(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(lc_dbg), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(lc_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 extern "C" int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, int ks,
                                                     int tile_cfg) {
