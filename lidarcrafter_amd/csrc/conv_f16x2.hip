@@ -593,7 +593,10 @@ struct DefEpi {
     static constexpr int NSLOT = DCH * NTAP;
     static constexpr int VPT = (NV + NSLOT - 1) / NSLOT;   // values per tap slot
     static constexpr int NUSED = (NV + VPT - 1) / VPT;     // slots that carry values
-    static constexpr int LAG = 3, RING = (LAG + 1) * VPT;
+#ifndef LC_DEF_LAG
+#define LC_DEF_LAG 10
+#endif
+    static constexpr int LAG = LC_DEF_LAG, RING = (LAG + 1) * VPT;   // residual loads run LAG taps ahead of their use
     static constexpr unsigned OOB = 0x80000000u;
     // Value order: k = ((i * 4 + m) * TPX + j) * 4 + q  <->  accumulator (i, j, r = 4 m + q): the 4 * TPX
     // values of one channel OCTET (m; registers 4m .. 4m+3 of both lane halves) are consecutive, so
@@ -650,9 +653,10 @@ struct DefEpi {
         rq[k % RING] = __builtin_bit_cast(
             float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off_of(k), (unsigned)cor_of(k) * HW4, 0));
     }
-    __device__ __forceinline__ void finalize(int k) {
+    __device__ __forceinline__ void finalize(int k) { finalize_with(k, rq[k % RING]); }
+    __device__ __forceinline__ void finalize_with(int k, float res) {
         const int i = i_of(k), m = m_of(k), j = j_of(k), r = 4 * m + (k & 3);
-        const float v = fmaf(accp[i][j][r], out_unscale, rq[k % RING]) * out_scale;
+        const float v = fmaf(accp[i][j][r], out_unscale, res) * out_scale;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, off_of(k),
                                               (unsigned)cor_of(k) * HW4, LC_DEF_AUX);
         if constexpr (EMIT) {
@@ -701,9 +705,20 @@ struct DefEpi {
         for (int s = 0; s < NUSED; ++s)
             if (s >= s0) slot(s);
     }
+    // the block's LAST tile drains in the open: nothing hides a residual load's latency there, so all
+    // of them are requested up front, into the (now dead) live accumulator registers
+    __device__ __forceinline__ void drain(f32x16 (&tmp)[TCO][TPX]) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            tmp[i_of(k)][j_of(k)][4 * m_of(k) + (k & 3)] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off_of(k), (unsigned)cor_of(k) * HW4, 0));
+#pragma unroll
+        for (int k = 0; k < NV; ++k) finalize_with(k, tmp[i_of(k)][j_of(k)][4 * m_of(k) + (k & 3)]);
+    }
     // park the finished tile at (h0, w0): accumulators, pixel offsets, statistics entry, first residuals
     __device__ __forceinline__ void begin(const f32x16 (&acc)[TCO][TPX], int h0, int w0, int H, int W,
-                                          int wpx, int lane, int tiles_w, int HWpx, int co_blk) {
+                                          int wpx, int lane, int tiles_w, int HWpx, int co_blk,
+                                          bool prefetch) {
         const int l31 = lane & 31;
         int nvalid = 0;
 #pragma unroll
@@ -722,9 +737,11 @@ struct DefEpi {
             nv8 = (float)(8 * nvalid);
             ent_off = lane == 63 ? (unsigned)(co_blk >> 3) * oct_stride + (unsigned)slot_id * 16u : OOB;
         }
+        if (prefetch) {                                 // (the last tile is drained with its own loads)
 #pragma unroll
-        for (int k = 0; k < LAG * VPT; ++k)
-            if (k < NV) issue_res(k);
+            for (int k = 0; k < LAG * VPT; ++k)
+                if (k < NV) issue_res(k);
+        }
     }
 };
 
@@ -1151,14 +1168,14 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         }
         for (int ch = DE::DCH; ch < nchunk; ++ch) iter(ch, -1);
         // park this tile; the accumulators restart from the bias
-        de.begin(acc, h0, w0, H, W, wpx, lane, a.tiles_w, HW, co0 + wco * C::TCO_ * 32);
-        acc_init();
+        de.begin(acc, h0, w0, H, W, wpx, lane, a.tiles_w, HW, co0 + wco * C::TCO_ * 32, more);
+        if (more) acc_init();
         h0 += dh; w0 += dw;
     }
 #if LC_TIMING
     const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
-    de.flush_from(0);                                  // the last tile drains in the open
+    de.drain(acc);                                     // the last tile drains in the open
 #if LC_TIMING
     t_epi = __builtin_amdgcn_s_memtime() - te0;
 #endif
