@@ -94,6 +94,56 @@ def cpu_baseline(n_steps: int = 2):
                       f"{dt:.1f} s wall"}
 
 
+def measure_hbm_traffic(timeout_s: int = 150):
+    """HBM-side bytes per launch of the dominant kernel family, MEASURED in this run: this script
+    re-executes itself for 4 steps under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, in a
+    separate pass, `--pmc WRITE_SIZE` (MI355X_MICROARCH.md HBM section: separate passes, units KB,
+    FETCH_SIZE x2 on gfx950 -- 128-byte fabric reads are tallied as 64 bytes -- WRITE_SIZE x1).
+    Returns (bytes_per_launch, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    tool = shutil.which("rocprofv3")
+    if tool is None:
+        return None, "rocprofv3 not on PATH"
+    totals = {}
+    tmp = tempfile.mkdtemp(prefix="lc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p",
+                   "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
+                   "--repeat", "1", "--no-verify", "--no-cpu-baseline", "--no-roofline"]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                k = row["Kernel_Name"]
+                if "conv_f16x2" in k and ("Li3EEEE" in k or ", 3>" in k):   # the 3x3 instantiations
+                    tot += float(row["Counter_Value"]) * 1024.0
+                    n += 1
+            if n == 0:
+                return None, f"no 3x3 conv launches in the {counter} pass"
+            totals[counter] = (tot, n)
+    except Exception as e:   # a missing tool / a refused counter must not cost the bench line
+        return None, f"PMC passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (f, nf), (w, nw) = totals["FETCH_SIZE"], totals["WRITE_SIZE"]
+    read, write = 2.0 * f / nf, w / nw
+    return read + write, {"read_bytes_per_launch": round(read), "write_bytes_per_launch": round(write),
+                          "launches_counted": nf}
+
+
 def verify_against_reference(ddpm, rank, world, device):
     """One DDIM step of the BENCH configuration (batch 8, 50-step schedule, x_T from CPU generators
     seeded with the global sample index -- exactly what the timed loop runs) and the full 50-step
@@ -136,6 +186,8 @@ def main():
                     help="skip the golden-vector check of the bench configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU,
                     help="samples per GPU (default 8 = the C2 workload; other values are "
                          "diagnostic and are named in config.workload)")
@@ -257,21 +309,34 @@ def main():
         achieved = w / t / 1e12
         split = K.CONV_PRECISION == "f16x2"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        traffic = None   # HBM-side bytes per launch of the dominant kernel, from a separate PMC pass
-        tfile = "r02_hbm_traffic.json" if os.path.exists(
-            os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) else "r01_i_hbm_traffic.json"
-        tpath = os.path.join(ROOT, "profiles", tfile)
-        if split and BATCH_PER_GPU == 8 and os.path.exists(tpath):
-            traffic = round(json.load(open(tpath))["conv3x3_bytes_per_launch"])
+        # HBM-side bytes per launch of the dominant kernel family: measured HERE (two PMC passes of
+        # this very script, N = 1 only), else the committed figure of an earlier profile, labelled
+        traffic, tsource, tdetail = None, None, None
+        if split and BATCH_PER_GPU == 8 and world == 1 and not args.no_traffic:
+            traffic, tdetail = measure_hbm_traffic()
+            if traffic is not None:
+                traffic = round(traffic)
+                tsource = ("MEASURED in this run: bench.py re-executed for 4 steps under rocprofv3 "
+                           "--kernel-trace --pmc FETCH_SIZE and, separately, --pmc WRITE_SIZE; FETCH_SIZE "
+                           "x2 (gfx950 correction), WRITE_SIZE x1, units KB; per 3x3 conv launch")
+        if traffic is None:
+            why = tdetail if isinstance(tdetail, str) else "--no-traffic / N > 1"
+            for tfile in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_i_hbm_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", tfile)
+                if split and BATCH_PER_GPU == 8 and os.path.exists(tpath):
+                    traffic = round(json.load(open(tpath))["conv3x3_bytes_per_launch"])
+                    tsource = (f"NOT measured in this run ({why}): read from profiles/{tfile} (rocprofv3 "
+                               "--pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate passes, same "
+                               "workload, devtools/hbm_traffic.py)")
+                    break
+            tdetail = None
         roof = {"bound": "mfma",
                 "kernel": ("conv_f16x2_kernel<KS=3>" if split else "conv_ring_kernel<KS=3>") +
                           " (all tile instantiations)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_source": (f"NOT measured in this run: read from profiles/{tfile} (rocprofv3 "
-                                   "--pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, separate "
-                                   "passes, same workload, devtools/hbm_traffic.py)"
-                                   if traffic else None),
+                "traffic_source": tsource, "traffic_detail": tdetail,
+                "algorithmic_bytes_per_launch": round(70.0e6) if BATCH_PER_GPU == 8 else None,
                 "note": ("achieved counts ALGORITHMIC flops (2*MACs); the f16x2 split issues 3 "
                          "f16 MFMAs per product, so the attainable ceiling of this kernel is "
                          "peak/3 = 833 TFLOP/s" if split else

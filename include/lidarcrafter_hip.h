@@ -277,6 +277,12 @@ int lc_attention_f16x2_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
  *   k0, k1, clip_range (<=0: no clip), unused}: ddpm k0 = c = -expm1(l_t-l_s), k1 = sigma_s*sqrt(c);
  *   ddim k0 = c1, k1 = c2.  objective: 0 eps, 1 v, 2 x_0.  mode: 0 ddpm, 1 ddim.
  *   noise may be NULL when its coefficient is 0 (ddim eta=0).  n = C*H*W per sample.
+ *   DiscreteTimeGaussianDiffusion.p_step discrete_time.py:126-180 (round 3): mode 2 ddpm, 3 ddim with
+ *   coef = {A, Bc, c2, c3, c4, c5, clip, c7}: x0 = A x_t - Bc pred (eps: A = rsqrt(ab), Bc =
+ *   sqrt(1/ab - 1); v: sqrt(ab), sqrt(1 - ab); x_0: x0 = pred); ddpm (c2 x0 + c3 x_t) + c4 noise with
+ *   c2 = sqrt(ab_prev) beta / (1 - ab), c3 = (1 - ab_prev) sqrt(alpha) / (1 - ab), c4 = sigma (0 at
+ *   step 0); ddim c4 x0 + c5 (x_t - c2 x0) / c3 [+ c7 noise] with c2 = sqrt(ab), c3 = sqrt(1 - ab),
+ *   c4 = sqrt(ab_prev), c5 = sqrt(1 - ab_prev - sd^2), c7 = sd.
  * ------------------------------------------------------------------------------------------- */
 int lc_pstep_fwd(const float* x_t, int64_t xt_bs, const float* pred, int64_t pred_bs,
                  const float* noise, int64_t noise_bs, const float* coef, float* x_s,

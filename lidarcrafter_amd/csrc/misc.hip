@@ -104,6 +104,23 @@ __global__ __launch_bounds__(256) void pstep_kernel(
         if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
         const float nz = np_ ? np_[i] : 0.f;
         float out;
+        if (mode >= 2) {
+            // discrete-time update (discrete_time.py:126-180), coefficient row
+            //   {A, Bc, c2, c3, c4, c5, clip, c7}: x0 = A xt - Bc pred (eps / v objectives) or pred;
+            //   mode 2 (ddpm): (c2 x0 + c3 xt) + c4 nz;  mode 3 (ddim): c4 x0 + c5 (xt - c2 x0) / c3 [+ c7 nz]
+            if (objective != 2) x0 = a_t * xt - s_t * pr;
+            if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+            if (mode == 2) {
+                const float mean = a_s * x0 + s_s * xt;
+                out = mean + k0 * nz;
+            } else {
+                const float eps = (xt - a_s * x0) / s_s;
+                out = k0 * x0 + k1 * eps;
+                if (np_) out = out + cf[7] * nz;
+            }
+            op[i] = out;
+            continue;
+        }
         if (mode == 0) {  // ddpm: k0 = c, k1 = sigma_s*sqrt(c)
             const float mean = a_s * (xt * (1.f - k0) / a_t + k0 * x0);
             out = mean + k1 * nz;
@@ -184,7 +201,7 @@ extern "C" int lc_pstep_fwd(const float* x_t, int64_t xt_bs, const float* pred, 
                             int64_t xs_bs, int B, int64_t n, int objective, int mode,
                             lc_stream_t s) {
     if (!x_t || !pred || !coef || !x_s || B <= 0 || n <= 0) return LC_EINVAL;
-    if (objective < 0 || objective > 2 || mode < 0 || mode > 1) return LC_EINVAL;
+    if (objective < 0 || objective > 2 || mode < 0 || mode > 3) return LC_EINVAL;
     hipLaunchKernelGGL(pstep_kernel, dim3(grid_for(n), B), dim3(256), 0, lc_s(s), x_t,
                        (long long)xt_bs, pred, (long long)pred_bs, noise, (long long)noise_bs, coef,
                        x_s, (long long)xs_bs, (long long)n, objective, mode);

@@ -1,7 +1,9 @@
 """Discrete-time DDPM/DDIM (https://arxiv.org/abs/2006.11239) -- API mirror of the reference's
 lidargen/models/diffusion/discrete_time.py:52-201.  Secondary: no shipped config selects it
-(SURVEY.md §2-1b); the denoiser forward is the same HIP path, the B-element table lookups and the
-update run as elementwise tensor ops."""
+(SURVEY.md §2-1b); the denoiser forward is the same HIP path and the update is the same fused
+kernel as the continuous-time samplers (`lc_pstep_fwd`, modes 2 / 3): the per-sample coefficients are
+tabulated on the host with the reference's fp32 torch expressions (bit-identical scalars), one
+[B, 8] row per step."""
 from __future__ import annotations
 
 from typing import Literal
@@ -60,39 +62,58 @@ class DiscreteTimeGaussianDiffusion(base.GaussianDiffusion):
         ab = self.alpha_bar[steps]
         return ab.sqrt() * x_0 + (1 - ab).sqrt() * noise, noise
 
-    @torch.compiler.disable
-    @torch.inference_mode()
-    def p_step(self, x_t, steps, rng=None, mode: Literal["ddpm", "ddim"] = "ddim", eta: float = 0.0):
-        beta, ab, abp = self.beta[steps], self.alpha_bar[steps], self.alpha_bar_prev[steps]
+    def _tables(self):
+        """CPU copies of the schedule buffers (the coefficient algebra runs on the host, in fp32,
+        with the reference's own expressions)."""
+        t = getattr(self, "_cpu_tables", None)
+        if t is None or t[0] is not self.beta:
+            t = (self.beta, self.beta.detach().cpu().reshape(-1), self.alpha_bar.detach().cpu().reshape(-1),
+                 self.alpha_bar_prev.detach().cpu().reshape(-1))
+            self._cpu_tables = t
+        return t[1:]
+
+    def step_coefficients(self, steps: torch.Tensor, mode: str, eta: float = 0.0) -> torch.Tensor:
+        """[B] integer steps -> [B, 8] coefficient rows of `lc_pstep_fwd` modes 2 (ddpm) / 3 (ddim):
+        reference discrete_time.py:126-180, every scalar computed by the same fp32 expression."""
+        if mode not in ("ddpm", "ddim"):
+            raise ValueError(f"invalid mode {mode}")
+        beta_t, ab_t, abp_t = self._tables()
+        idx = steps.detach().cpu().long()
+        beta, ab, abp = beta_t[idx], ab_t[idx], abp_t[idx]
         alpha = 1 - beta
-        pred = self.model(x_t, steps)
+        zero = torch.zeros_like(ab)
         if self.objective == "eps":
-            x_0 = ab.rsqrt() * x_t - (ab.reciprocal() - 1).sqrt() * pred
-        elif self.objective == "x_0":
-            x_0 = pred
+            A, Bc = ab.rsqrt(), (ab.reciprocal() - 1).sqrt()
         elif self.objective == "v":
-            x_0 = ab.sqrt() * x_t - (1 - ab).sqrt() * pred
+            A, Bc = ab.sqrt(), (1 - ab).sqrt()
+        elif self.objective == "x_0":
+            A, Bc = zero, zero
         else:
             raise ValueError(f"invalid objective {self.objective}")
-        if self.clip_sample:
-            x_0 = x_0.clamp(-self.clip_sample_range, self.clip_sample_range)
+        clip = torch.full_like(ab, float(self.clip_sample_range) if self.clip_sample else 0.0)
+        live = (idx != 0).float()                                  # `nz[steps == 0] *= 0`
         if mode == "ddpm":
-            mean = abp.sqrt() * beta / (1 - ab) * x_0 + (1 - abp) * alpha.sqrt() / (1 - ab) * x_t
+            c2 = abp.sqrt() * beta / (1 - ab)
+            c3 = (1 - abp) * alpha.sqrt() / (1 - ab)
             var = (beta * (1 - abp) / (1 - ab)).clamp(min=1e-20)
-            nz = self.randn_like(x_t, rng=rng)
-            nz[steps == 0] *= 0
-            return mean + (0.5 * var.log()).exp() * nz
-        if mode == "ddim":
+            c4 = (0.5 * var.log()).exp() * live
+            rows = [A, Bc, c2, c3, c4, zero, clip, zero]
+        else:
             var = (1 - abp) / (1 - ab) * (1 - ab / abp)
             sd = eta * var.sqrt()
-            eps = (x_t - ab.sqrt() * x_0) / (1 - ab).sqrt()
-            x_s = abp.sqrt() * x_0 + (1 - abp - sd ** 2).sqrt() * eps
-            if eta > 0:
-                nz = self.randn_like(x_t, rng=rng)
-                nz[steps == 0] *= 0
-                x_s = x_s + sd * nz
-            return x_s
-        raise ValueError(f"invalid mode {mode}")
+            rows = [A, Bc, ab.sqrt(), (1 - ab).sqrt(), abp.sqrt(), (1 - abp - sd ** 2).sqrt(), clip, sd * live]
+        return torch.stack(rows, dim=1).float().contiguous()
+
+    @torch.compiler.disable
+    @torch.inference_mode()
+    def p_step(self, x_t, steps, rng=None, mode: Literal["ddpm", "ddim"] = "ddim", eta: float = 0.0,
+               coef: torch.Tensor = None):
+        if coef is None:
+            coef = self.step_coefficients(steps, mode, eta).to(x_t.device)
+        pred = self.model(x_t, steps)
+        noise = self.randn_like(x_t, rng=rng) if (mode == "ddpm" or eta > 0) else None
+        return K.pstep(x_t, pred, noise, coef, schedules.OBJECTIVES[self.objective],
+                       2 if mode == "ddpm" else 3)
 
     @torch.inference_mode()
     def sample(self, batch_size, num_steps, progress=True, rng=None, return_all=False,
@@ -100,10 +121,13 @@ class DiscreteTimeGaussianDiffusion(base.GaussianDiffusion):
         def run():
             x = self.randn(batch_size, *self.sampling_shape, rng=rng, device=self.device)
             out = [x] if return_all else None
-            for ts in tqdm(list(reversed(range(num_steps))), desc="sampling", leave=False,
-                           disable=not progress):
+            order = list(reversed(range(num_steps)))
+            # all coefficient rows of the run in ONE host tabulation + ONE upload
+            table = self.step_coefficients(torch.tensor(order).repeat_interleave(batch_size), mode)
+            table = table.view(num_steps, batch_size, 8).to(self.device)
+            for i, ts in enumerate(tqdm(order, desc="sampling", leave=False, disable=not progress)):
                 steps = torch.full((batch_size,), ts, device=self.device).long()
-                x = self.p_step(x, steps, rng=rng, mode=mode)
+                x = self.p_step(x, steps, rng=rng, mode=mode, coef=table[i])
                 if return_all:
                     out.append(x)
             return torch.stack(out) if return_all else x
