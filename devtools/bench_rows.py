@@ -196,7 +196,8 @@ def pib(dev, N, nbox):
 
 def train_step(dev, B):
     """One training step of the C2 denoiser through the HIP autograd Functions (forward + backward +
-    AdamW), tools/train/train_lidm.py:214-265 at batch B, fp32-MFMA convolutions."""
+    AdamW), tools/train/train_lidm.py:214-265 at batch B."""
+    from lidarcrafter_amd import autograd as AGm
     from lidarcrafter_amd.testing import seeded_fill
     from lidargen.utils import inference
     from lidargen.utils.configs import __all__ as C
@@ -217,7 +218,10 @@ def train_step(dev, B):
     flop = 3 * B * GFLOP["uncond32"] * 1e9                       # forward + dX + dW
     return {"batch": B, "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2),
             "algorithmic_tflops": round(flop / dt / 1e12, 1),
-            "note": "forward + backward + AdamW, exact-fp32 MFMA convolutions (LC_TRAIN_CONV_PRECISION=f32)"}
+            "train_conv_precision": AGm.TRAIN_CONV_PRECISION,
+            "note": "forward + backward + AdamW; forward / dX convolutions in the precision named by "
+                    "train_conv_precision (lidarcrafter_amd.autograd.TRAIN_CONV_PRECISION, env "
+                    "LC_TRAIN_CONV_PRECISION; default f16x2 split), weight gradient exact-fp32 MFMA"}
 
 
 def train_step_cond(dev, B):

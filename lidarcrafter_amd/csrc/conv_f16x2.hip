@@ -374,8 +374,12 @@ __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void con
                 const int row = e / BN;                    // tap*CB + cb
                 const int cu = e - row * BN;
                 const int tap = row / CB, cb = row - tap * CB;
-                const bool in = (c0 >> 3) + cb < a.Cib;         // the last chunk may be partial
-                const long long idx = ((long long)tap * a.Cib + (in ? (c0 >> 3) + cb : 0)) * a.Cop + co0 + cu;
+                // the last chunk may be partial; a block wider than the packed rows (BN = 128 with
+                // Cop = 64) must not read past them -- past the END of the allocation for the last row
+                // (a latent out-of-bounds read that faulted once the test order put the weights at the
+                // end of a mapped segment, round 3)
+                const bool in = (c0 >> 3) + cb < a.Cib && co0 + cu < a.Cop;
+                const long long idx = ((long long)tap * a.Cib + (in ? (c0 >> 3) + cb : 0)) * a.Cop + (in ? co0 + cu : 0);
                 const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 whr[i] = in ? a.wh[idx] : z;
                 wlr[i] = in ? a.wl[idx] : z;
