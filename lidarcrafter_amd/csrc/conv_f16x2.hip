@@ -600,7 +600,8 @@ struct DefEpi {
 #ifndef LC_DEF_LAG
 #define LC_DEF_LAG 10
 #endif
-    static constexpr int LAG = LC_DEF_LAG, RING = (LAG + 1) * VPT;   // residual loads run LAG taps ahead of their use
+    // residual loads run LAG slots ahead of their use (one slot per chunk for a 1x1 conv: many values per slot)
+    static constexpr int LAG = NTAP == 1 ? 1 : LC_DEF_LAG, RING = (LAG + 1) * VPT;
     static constexpr unsigned OOB = 0x80000000u;
     // Value order: k = ((i * 4 + m) * TPX + j) * 4 + q  <->  accumulator (i, j, r = 4 m + q): the 4 * TPX
     // values of one channel OCTET (m; registers 4m .. 4m+3 of both lane halves) are consecutive, so
