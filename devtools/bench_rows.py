@@ -65,10 +65,14 @@ def cond(dev, B, steps):
     rng = [torch.Generator().manual_seed(i) for i in range(B)]
     with torch.inference_mode():
         x_T = ddpm.randn(B, *ddpm.sampling_shape, rng=rng, device=ddpm.device)
-        t0 = time.perf_counter()
-        cdict = ddpm.get_network_condition(input_dict=batch, only_custom_condition=True)
-        torch.cuda.synchronize()
-        t_enc = time.perf_counter() - t0
+        t_first = None
+        for _ in range(3):   # the first call of a process also pays the one-time costs (weight
+            torch.cuda.synchronize()   # packing, code-object load, rocBLAS init for the Linears)
+            t0 = time.perf_counter()
+            cdict = ddpm.get_network_condition(input_dict=batch, only_custom_condition=True)
+            torch.cuda.synchronize()
+            t_enc = time.perf_counter() - t0
+            t_first = t_enc if t_first is None else t_first
         st = ddpm.begin_sampling(B, steps + 3, None, "ddim", 0.0, x_T=x_T, condition_dict=cdict)
         dt = timed(lambda: ddpm.sampling_step(st), steps, warm=3)
         x = st["x"]
@@ -77,7 +81,8 @@ def cond(dev, B, steps):
             "steps_per_s": round(1 / dt, 2), "sample_steps_per_s": round(B / dt, 1),
             "algorithmic_tflops": round(B * GFLOP["cond32"] / dt / 1e3, 1),
             "frac_of_f16_mfma_peak": round(B * GFLOP["cond32"] / dt / 1e3 / 2500.0, 4),
-            "layout_encoder_ms_once_per_batch": round(t_enc * 1e3, 2)}
+            "layout_encoder_ms_once_per_batch": round(t_enc * 1e3, 2),
+            "layout_encoder_first_call_ms": round(t_first * 1e3, 2)}
 
 
 def sequence(dev, B, frames, steps):

@@ -1,0 +1,16 @@
+# Round-3 evidence run (on the MI355X box via gpurun): bash devtools/round_end_r03.sh TAG [notest]
+export TMPDIR=/tmp
+T=${1:-r03a}
+O=$PWD/gpurun_out/$T
+mkdir -p $O
+if [ "$2" != "notest" ]; then
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > $O/smoke.txt
+fi
+timeout 600 python bench.py 2>&1 | tail -1 > $O/bench.json
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --repeat 1 --no-verify --no-cpu-baseline --no-roofline > $O/prof.log 2>&1)
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profc -o k -- python $GRAFT_REPO_ROOT/devtools/cond_run.py 8 12 > $O/profc.log 2>&1)
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -o k -- python $GRAFT_REPO_ROOT/bench.py --batch 1 --steps 20 --warmup 3 --repeat 1 --no-verify --no-cpu-baseline --no-roofline > $O/prof1.log 2>&1)
+find $O -name "*kernel_trace.csv" -delete
+timeout 600 python devtools/bench_rows.py > $O/rows.json 2> $O/rows.err
+cat $O/pytest.txt $O/smoke.txt 2>/dev/null; head -c 1500 $O/bench.json; echo; du -sh $O

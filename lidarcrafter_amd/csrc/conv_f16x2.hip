@@ -168,6 +168,15 @@ template <int NT>
 __device__ __forceinline__ void gn_rows_from_ostats(const ConvArgsH& a, int b, int tid, f32x4* ctab,
                                                     float2* gtab) {
     const int G = a.gs.G, cpg = a.Ci / G, lane = tid & 63;
+    // the affine inputs of this thread's first channel do not depend on the fold: request them first
+    // (as loads behind the fold's barrier they were one more exposed miss in every block's prologue)
+    float ga0 = 1.0f, be0 = 0.0f, sc0 = 1.0f, sh0 = 0.0f;
+    if (tid < a.Ci) {
+        if (a.gs.gamma) ga0 = a.gs.gamma[tid];
+        if (a.gs.beta) be0 = a.gs.beta[tid];
+        if (a.gs.scale) sc0 = 1.0f + a.gs.scale[b * a.gs.ss_bs + tid];
+        if (a.gs.shift) sh0 = a.gs.shift[b * a.gs.ss_bs + tid];
+    }
     for (int g = tid >> 6; g < G; g += NT / 64) {
         const int cg0 = g * cpg;
         const bool s1 = cg0 >= a.seg[0].channels;
@@ -178,13 +187,13 @@ __device__ __forceinline__ void gn_rows_from_ostats(const ConvArgsH& a, int b, i
         const int n_ent = (cpg >> 3) * slots;
         const double P0 = (double)e[0].x;
         double N = 0.0, S = 0.0, Q = 0.0;
-        for (int base = lane; base < n_ent; base += 64 * 8) {   // 8 loads in flight per lane
-            f32x4 v[8];
+        for (int base = lane; base < n_ent; base += 64 * 16) {   // 16 loads in flight per lane
+            f32x4 v[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < 16; ++k)
                 v[k] = base + 64 * k < n_ent ? e[base + 64 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {                       // an absent entry (n = 0) adds nothing
+            for (int k = 0; k < 16; ++k) {                      // an absent entry (n = 0) adds nothing
                 const double n = v[k].y, d = (double)v[k].x - P0, s_ = v[k].z;
                 N += n;
                 S += s_ + n * d;
@@ -205,9 +214,12 @@ __device__ __forceinline__ void gn_rows_from_ostats(const ConvArgsH& a, int b, i
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (c < a.Ci) {
             const float2 ms = gtab[c / cpg];
-            const float ga = a.gs.gamma ? a.gs.gamma[c] : 1.0f, be = a.gs.beta ? a.gs.beta[c] : 0.0f;
-            const float sc = a.gs.scale ? 1.0f + a.gs.scale[b * a.gs.ss_bs + c] : 1.0f;
-            const float sh = a.gs.shift ? a.gs.shift[b * a.gs.ss_bs + c] : 0.0f;
+            float ga = ga0, be = be0, sc = sc0, sh = sh0;
+            if (c != tid) {
+                ga = a.gs.gamma ? a.gs.gamma[c] : 1.0f; be = a.gs.beta ? a.gs.beta[c] : 0.0f;
+                sc = a.gs.scale ? 1.0f + a.gs.scale[b * a.gs.ss_bs + c] : 1.0f;
+                sh = a.gs.shift ? a.gs.shift[b * a.gs.ss_bs + c] : 0.0f;
+            }
             r.x = ms.x; r.y = ms.y * ga * sc; r.z = be * sc + sh;
         }
         ctab[c] = r;
@@ -713,6 +725,9 @@ struct DefEpi {
     // the block's LAST tile drains in the open: nothing hides a residual load's latency there, so all
     // of them are requested up front, into the (now dead) live accumulator registers
     __device__ __forceinline__ void drain(f32x16 (&tmp)[TCO][TPX]) {
+#ifdef LC_NO_DRAIN   // developer timing build: what does the open drain cost?  (wrong results)
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             tmp[i_of(k)][j_of(k)][4 * m_of(k) + (k & 3)] = __builtin_bit_cast(
@@ -761,6 +776,9 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     constexpr int XR = C::XR, XW = C::XW, XU = C::XU, WU = C::WU, NWU = C::NWU;
     constexpr int KS = 2 * HALO + 1;
     constexpr int NT = C::NT, NWV = NT / 64;
+#if LC_TIMING
+    const unsigned long long t_enter = __builtin_amdgcn_s_memtime();
+#endif
     // x staging units: a wave-instruction covers 64 consecutive positions of ONE 8-channel block
     // (wave-unit j = wave + NWV * i  ->  block j / WPC), so the GroupNorm rows of a unit are the same
     // for all lanes and the channel block is a scalar.
@@ -1188,6 +1206,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 #if LC_TIMING
     if (lane == 0) {
         atomicAdd(&lc_dbg[0], __builtin_amdgcn_s_memtime() - t_start);   // wave lifetime from the prologue's end
+        atomicAdd(&lc_dbg[1], t_start - t_enter);
         atomicAdd(&lc_dbg[2], t_comp);
         atomicAdd(&lc_dbg[3], t_bar);
         atomicAdd(&lc_dbg[4], t_epi);

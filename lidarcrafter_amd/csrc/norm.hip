@@ -561,6 +561,10 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
 static int split_slabs(int B, int C, long long HW) {
     int slabs = (int)((HW + 2047) / 2048);                 // >= 2048 pixels (x 8 channels) per block
     if (slabs < 1) slabs = 1;
+    // small batches: 1024 pixels (one pass of the vector loop), then 512, while < 4 blocks per CU exist
+    // (batch 1: 32-64 blocks of two serial passes each took 8.5 us per launch, profiles/r03_small_batch.txt)
+    if ((long long)B * (C / 8) * slabs < 1024 && HW % 1024 == 0) slabs = (int)(HW / 1024);
+    if ((long long)B * (C / 8) * slabs < 1024 && HW % 512 == 0) slabs = (int)(HW / 512);
     while (slabs > 1 && (long long)B * (C / 8) * slabs > 8192) slabs = (slabs + 1) / 2;
     return slabs;
 }
