@@ -327,6 +327,17 @@ int64_t lc_conv2d_ring_wgrad_scratch_elems(int B, int Ci, int Co, int H, int W, 
 int lc_conv2d_ring_wgrad(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, float* scratch,
                          float* dw /* [Co,Ci,ks,ks] */, float* dbias /* [Co] or NULL */, int B, int Ci,
                          int Co, int H, int W, int ks, int accumulate, lc_stream_t s);
+/* The same gradient on the f16 matrix cores with the operand split of the f16x2 forward (3 MFMAs per
+ * product, per-product error ~2^-22, fp32 accumulation; contraction over pixels, which NCHW stores
+ * contiguously -- no transposition): x and dy are pre-scaled by the power-of-two x_scale of
+ * `x_range` / `dy_range` (records of exactly these tensors: lc_range_from_tensor right before the
+ * forward conv of x and the input-gradient conv of dy, lidarcrafter_amd/autograd.py) and the result
+ * is unscaled by both.  Needs H even, W % 32 == 0 and 16-byte aligned rows (LC_EUNSUP otherwise: use
+ * lc_conv2d_ring_wgrad); scratch and everything else as lc_conv2d_ring_wgrad. */
+int lc_conv2d_ring_wgrad_f16x2(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                               const lc_conv_range* x_range, const lc_conv_range* dy_range,
+                               float* scratch, float* dw, float* dbias, int B, int Ci, int Co, int H,
+                               int W, int ks, int accumulate, lc_stream_t s);
 int lc_groupnorm_meanrstd(const float* x, int64_t x_bs, const double* partials, float* mean_rstd,
                           int B, int C, int H, int W, int G, float eps, lc_stream_t s);
 int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,

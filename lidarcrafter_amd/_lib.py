@@ -73,6 +73,8 @@ SIGNATURES = {
                                     i32, i32, f32, i32, vp]),
     "lc_conv2d_ring_wgrad_scratch_elems": (i64, [i32, i32, i32, i32, i32, i32]),
     "lc_conv2d_ring_wgrad": (i32, [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "lc_conv2d_ring_wgrad_f16x2": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+                                         i32, i32, vp]),
     "lc_groupnorm_meanrstd": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "lc_groupnorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32,
                                i32, i32, i32, vp]),

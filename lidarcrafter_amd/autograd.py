@@ -9,7 +9,7 @@ training takes a second, plain composition of the same layers in which every hea
 
   ConvRing      forward  lc_conv2d_ring_*_fwd
                 backward dX: the same ring convolution of dY with the transposed, 180-degree rotated
-                         kernel (forward kernel);  dW, db: lc_conv2d_ring_wgrad (fp32 MFMA implicit
+                         kernel (forward kernel);  dW, db: lc_conv2d_ring_wgrad[_f16x2] (MFMA implicit
                          GEMM over pixels, deterministic two-stage reduction)
   GroupNormAct  forward  lc_groupnorm_stats + lc_groupnorm_apply (+ AdaGN scale/shift, + SiLU)
                 backward lc_groupnorm_bwd (rows + dx); parameter gradients contracted from the rows
@@ -37,8 +37,10 @@ from ._lib import check, lib
 # arithmetic of the forward / dX convolutions inside the training graph: "f16x2" = the split kernels
 # (fp32-class accuracy; the pre-scale of every operand -- activation or gradient -- is measured on
 # the device right before its conv, K.range_from_tensor), "f32" = exact-fp32 MFMA kernels.
-# The weight-gradient kernel is exact fp32 either way.
 TRAIN_CONV_PRECISION = os.environ.get("LC_TRAIN_CONV_PRECISION", "f16x2")
+# ... and of the weight gradient: "f16x2" = lc_conv2d_ring_wgrad_f16x2 (same split, same records; used
+# when the forward / dX convs are split too and the shape has whole 2 x 32 tiles), "f32" = exact fp32.
+TRAIN_WGRAD_PRECISION = os.environ.get("LC_TRAIN_WGRAD_PRECISION", "f16x2")
 
 
 def training_active(module: torch.nn.Module, *tensors) -> bool:
@@ -88,22 +90,36 @@ class ConvRing(torch.autograd.Function):
         B, Ci, H, W = x.shape
         Co, ks = weight.shape[0], weight.shape[-1]
         dx = dw = db = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        # the split weight gradient needs whole 2 x 32 pixel tiles and 16-byte aligned rows
+        w_split = (need_w and TRAIN_WGRAD_PRECISION == "f16x2" and TRAIN_CONV_PRECISION == "f16x2" and
+                   H % 2 == 0 and W % 32 == 0 and _bs(x) % 4 == 0 and _bs(dy) % 4 == 0 and
+                   x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+        if TRAIN_CONV_PRECISION == "f16x2" and (ctx.needs_input_grad[0] or w_split):
+            K.range_from_tensor(dy, ctx.holder["bwd"])         # one measurement serves dX and dW
         if ctx.needs_input_grad[0]:
             wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [Ci, Co, ks, ks]
-            if TRAIN_CONV_PRECISION == "f16x2":
-                K.range_from_tensor(dy, ctx.holder["bwd"])
             dx = K.conv2d_ring(dy, ctx.holder["bwd"], wt, None, precision=TRAIN_CONV_PRECISION)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if need_w:
             dw = torch.empty_like(weight)
             db = torch.empty(Co, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             n = int(lib().lc_conv2d_ring_wgrad_scratch_elems(B, Ci, Co, H, W, ks))
             scratch = torch.empty(n, device=x.device, dtype=torch.float32)
             with torch.cuda.device(x.device):
-                check(lib().lc_conv2d_ring_wgrad(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy),
-                                                 scratch.data_ptr(), dw.data_ptr(),
-                                                 None if db is None else db.data_ptr(), B, Ci, Co, H,
-                                                 W, ks, 0, torch.cuda.current_stream().cuda_stream),
-                      "lc_conv2d_ring_wgrad")
+                st = torch.cuda.current_stream().cuda_stream
+                if w_split:
+                    # x's record is the one its forward conv split with (nothing re-measures it in
+                    # between: a module's backward follows its own forward)
+                    check(lib().lc_conv2d_ring_wgrad_f16x2(
+                        x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy),
+                        ctx.holder["fwd"].range_ptr(x.device), ctx.holder["bwd"].range_ptr(x.device),
+                        scratch.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), B, Ci,
+                        Co, H, W, ks, 0, st), "lc_conv2d_ring_wgrad_f16x2")
+                else:
+                    check(lib().lc_conv2d_ring_wgrad(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy),
+                                                     scratch.data_ptr(), dw.data_ptr(),
+                                                     None if db is None else db.data_ptr(), B, Ci, Co, H,
+                                                     W, ks, 0, st), "lc_conv2d_ring_wgrad")
         return dx, dw, db, None
 
 

@@ -18,7 +18,9 @@ def dev():
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(2, 5, 7, 4, 16, 3), (1, 64, 64, 8, 128, 3), (2, 96, 130, 5, 50, 3),
-                                            (2, 64, 32, 4, 200, 1), (1, 128, 256, 4, 128, 3)])
+                                            (2, 64, 32, 4, 200, 1), (1, 128, 256, 4, 128, 3),
+                                            # whole 2 x 32 pixel tiles: the f16x2-split weight gradient
+                                            (2, 5, 7, 4, 32, 3), (2, 64, 32, 4, 64, 1), (3, 96, 130, 6, 96, 3)])
 def test_conv_gradients(dev, B, Ci, Co, H, W, ks):
     from lidarcrafter_amd import autograd as AG
     from oracle import denoiser as D
@@ -43,6 +45,39 @@ def test_conv_gradients(dev, B, Ci, Co, H, W, ks):
     assert rel_l2(xd.grad, xr.grad) < 2e-6, rel_l2(xd.grad, xr.grad)
     assert rel_l2(m.weight.grad, wr.grad) < 2e-6, rel_l2(m.weight.grad, wr.grad)
     assert rel_l2(m.bias.grad, br.grad) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(8, 64, 64, 32, 1024, 3), (4, 128, 64, 16, 512, 3), (2, 192, 128, 8, 256, 1),
+                                            (1, 34, 64, 32, 1024, 3), (2, 64, 2, 32, 1024, 3)])
+def test_split_weight_gradient_vs_exact_fp32(dev, B, Ci, Co, H, W, ks):
+    """lc_conv2d_ring_wgrad_f16x2 against the exact-fp32 kernel at full sizes (both deterministic), with
+    gradients 1e-4 x the activations' magnitude (each operand has its own range record), dW and db."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd._lib import check, lib
+
+    x = (seeded_randn(B, Ci, H, W, seed=21) * 3).to(dev)
+    dy = (seeded_randn(B, Co, H, W, seed=22) * 1e-4).to(dev)
+    rx, rdy = K.PackedConv("t.x"), K.PackedConv("t.dy")
+    K.range_from_tensor(x, rx)
+    K.range_from_tensor(dy, rdy)
+    n = int(lib().lc_conv2d_ring_wgrad_scratch_elems(B, Ci, Co, H, W, ks))
+    out = []
+    for split in (False, True):
+        scratch = torch.empty(n, device=dev)
+        dw, db = torch.empty(Co, Ci, ks, ks, device=dev), torch.empty(Co, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        bs = lambda t: t.shape[1] * H * W
+        if split:
+            check(lib().lc_conv2d_ring_wgrad_f16x2(x.data_ptr(), bs(x), dy.data_ptr(), bs(dy), rx.range_ptr(dev),
+                                                   rdy.range_ptr(dev), scratch.data_ptr(), dw.data_ptr(),
+                                                   db.data_ptr(), B, Ci, Co, H, W, ks, 0, st), "wgrad_f16x2")
+        else:
+            check(lib().lc_conv2d_ring_wgrad(x.data_ptr(), bs(x), dy.data_ptr(), bs(dy), scratch.data_ptr(),
+                                             dw.data_ptr(), db.data_ptr(), B, Ci, Co, H, W, ks, 0, st), "wgrad")
+        out.append((dw, db))
+    assert torch.isfinite(out[1][0]).all()
+    assert rel_l2(out[1][0], out[0][0]) < 2e-6, rel_l2(out[1][0], out[0][0])
+    assert torch.equal(out[1][1], out[0][1])
 
 
 @pytest.mark.parametrize("B,C,H,W,G", [(2, 16, 4, 8, 8), (1, 64, 8, 128, 8), (3, 96, 5, 50, 32)])
