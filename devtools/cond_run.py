@@ -16,6 +16,13 @@ seeded_fill(model, salt=200), seeded_fill(ddpm.condition_model, salt=201)
 ddpm = ddpm.eval().to(dev)
 batch = {k: v.to(dev) for k, v in synth_layout_batch(B, 32, 1024, seed=53).items()}
 rng = [torch.Generator().manual_seed(i) for i in range(B)]
+if os.environ.get("LC_GN_TRACE"):
+    import collections
+    from lidarcrafter_amd import ops as K
+    K.GN_TRACE = collections.Counter()
 x = ddpm.sample(batch, B, S, progress=False, rng=rng, mode="ddim")
 torch.cuda.synchronize()
 print("ok", float(x.abs().mean()))
+if os.environ.get("LC_GN_TRACE"):
+    for k, v in sorted(K.GN_TRACE.items(), key=lambda kv: (kv[0][2], kv[0][0])):
+        print("gn lookup", k, v)

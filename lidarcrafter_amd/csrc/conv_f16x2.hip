@@ -1663,8 +1663,13 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     const long long px = (long long)B * H * W;
     auto blocks = [&](int bn, int pxb) { return ((Co + bn - 1) / bn) * ((px + pxb - 1) / pxb); };
     const bool t256 = H % 4 == 0 && W % 64 == 0, t128 = H % 2 == 0 && W % 64 == 0;
-    if (ks == 1)    // one tap per chunk: nothing to pipeline, two resident blocks per CU win (1.3-2x)
+    if (ks == 1) {  // one tap per chunk: nothing to pipeline, two resident blocks per CU win (1.3-2x) ...
+        // ... except when the 256-pixel tiles are exactly one round of blocks: then the pipelined kernel
+        // with the deferred epilogue is ahead (256 -> 256 @ 8 x 8 x 256 + residual: 23.0 vs 37.5 us,
+        // 512 -> 256: 34.3 vs 38.1, profiles/r03_conv_phases.txt r03m) and can emit GroupNorm statistics
+        if (t256 && blocks(64, 256) > 192 && blocks(64, 256) <= 256) return 23;
         return (t128 && blocks(64, 128) >= 512) ? 5 : 3;
+    }
     if (Ci >= 24) {    // 8-wave pipelined, persistent blocks: 230-333 TF when >= 1 block per CU
                        // exists (also the 32-channel input layer: 41 vs 70 us on the other kernel)
         if (Co <= 32 && t256 && blocks(64, 256) >= 256) return 28;   // output head (Co = 2)

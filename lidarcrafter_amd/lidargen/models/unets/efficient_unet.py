@@ -302,12 +302,12 @@ class EfficientUNet(nn.Module):
         cat2 = cat_buf(2 * C[2], H // 2, W // 2)
         cat3 = cat_buf(2 * C[3], H // 4, W // 4)
         h = self.in_conv(buf)
-        h1 = self.d_block1(h, temb, ssd["d_block1"], out=cat1[:, C[1]:])
-        h2 = self.d_block2(h1, temb, ssd["d_block2"], out=cat2[:, C[2]:])
-        h3 = self.d_block3(h2, temb, ssd["d_block3"], out=cat3[:, C[3]:])
+        h1 = self.d_block1(h, temb, ssd["d_block1"], out=K.chan_slice(cat1, C[1], 2 * C[1]))
+        h2 = self.d_block2(h1, temb, ssd["d_block2"], out=K.chan_slice(cat2, C[2], 2 * C[2]))
+        h3 = self.d_block3(h2, temb, ssd["d_block3"], out=K.chan_slice(cat3, C[3], 2 * C[3]))
         h4 = self.d_block4(h3, temb, ssd["d_block4"])
-        self.u_block4(h4, temb, ssd["u_block4"], out=cat3[:, : C[3]])
-        self.u_block3(cat3, temb, ssd["u_block3"], out=cat2[:, : C[2]])
-        self.u_block2(cat2, temb, ssd["u_block2"], out=cat1[:, : C[1]])
+        self.u_block4(h4, temb, ssd["u_block4"], out=K.chan_slice(cat3, 0, C[3]))
+        self.u_block3(cat3, temb, ssd["u_block3"], out=K.chan_slice(cat2, 0, C[2]))
+        self.u_block2(cat2, temb, ssd["u_block2"], out=K.chan_slice(cat1, 0, C[1]))
         h = self.u_block1(cat1, temb, ssd["u_block1"])
         return self.out_conv(h)

@@ -153,7 +153,10 @@ class ObjectAwareCrossAttention(nn.Module):
     def forward(self, x, cond_kwargs, out=None):
         B, C, H, W = x.shape
         L1 = H * W
-        xs = x.reshape(B, C, L1) if x.is_contiguous() else x.contiguous().view(B, C, L1)
+        if K._dense_plane(x):   # token view of the same memory (a concat-buffer slice included)
+            xs = K.alias(torch.as_strided(x, (B, C, L1), (x.stride(0), L1, 1)), x)
+        else:
+            xs = x.contiguous().view(B, C, L1)
         pos_img, pos_lay, k_lay, v_lay = self.condition_operands(cond_kwargs)
         if K.fuse_gn(3 * C):
             qkv = self.qkv_projector(xs, gn_coeffs=gn32_coeffs(self.norm_for_qkv, xs))
@@ -164,8 +167,9 @@ class ObjectAwareCrossAttention(nn.Module):
         a = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale,
                            k2=k_lay, v2=v_lay, q_pos=pos_img, k_pos=pos_img, k2_pos=pos_lay)
         o3 = None if out is None else out
-        y = self.proj_out(a, res=xs, out=None if o3 is None else _as3(o3))
-        return (y.view(B, C, H, W) if out is None else out), None
+        # (statistics for the next block's GroupNorm: they follow the tensor through the token view)
+        y = self.proj_out(a, res=xs, out=None if o3 is None else K.alias(_as3(o3), o3), emit_stats=True)
+        return (K.alias(y.view(B, C, H, W), y) if out is None else out), None
 
 
 def _ver(t):
@@ -379,13 +383,13 @@ class LayoutUnetV1(nn.Module):
         h = buf
         for i, blk in enumerate(self.input_blocks):
             j = n_in - 1 - i
-            dst = cats[j][:, first[j] - self._skip_chans[i]:]
+            dst = K.chan_slice(cats[j], first[j] - self._skip_chans[i], first[j])
             h, _ = blk(h, emb, lay, scale_shifts=ssi, out=dst)
-        dst = cats[0][:, : first[0] - self._skip_chans[n_in - 1]]
+        dst = K.chan_slice(cats[0], 0, first[0] - self._skip_chans[n_in - 1])
         self.middle_block(h, emb, lay, scale_shifts=ssi, out=dst)
         for j, blk in enumerate(self.output_blocks):
             if j + 1 < len(self.output_blocks):
-                dst = cats[j + 1][:, : first[j + 1] - self._skip_chans[n_in - 2 - j]]
+                dst = K.chan_slice(cats[j + 1], 0, first[j + 1] - self._skip_chans[n_in - 2 - j])
             else:
                 dst = None
             h, _ = blk(cats[j], emb, lay, scale_shifts=ssi, out=dst)

@@ -3,6 +3,7 @@ lidargen/models/unets/nn.py (GroupNorm32 :17-19, conv_nd :22-31, conv_nd_range :
 linear :46-50, zero_module :79-85, normalization :104-111), HIP-backed where they compute."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from lidarcrafter_amd import ops as K
@@ -29,18 +30,25 @@ class GroupNorm32(nn.GroupNorm):
         if x.dim() == 3:
             B, C, L = x.shape
             o4 = None if out is None else out.view(B, C, 1, L)
-            y = K.groupnorm(x.reshape(B, C, 1, L), self.num_groups, self.eps, self.weight,
+            y = K.groupnorm(_tok4(x), self.num_groups, self.eps, self.weight,
                             self.bias, scale, shift, act_silu=act_silu, out=o4)
             return y.view(B, C, L)
         return K.groupnorm(x, self.num_groups, self.eps, self.weight, self.bias, scale, shift,
                            act_silu=act_silu, out=out)
 
 
+def _tok4(x3):
+    """[B,C,L] (batch stride arbitrary, rows dense) -> [B,C,1,L] view that keeps the producer statistics."""
+    B, C, L = x3.shape
+    if x3.stride(2) == 1 and x3.stride(1) == L:
+        return K.alias(torch.as_strided(x3, (B, C, 1, L), (x3.stride(0), L, L, 1)), x3)
+    return x3.reshape(B, C, 1, L)
+
+
 def gn32_coeffs(norm: "GroupNorm32", x, scale=None, shift=None):
     """Statistics pass of a GroupNorm32 on [B,C,H,W] / [B,C,L] -> rows for the fused conv input."""
     if x.dim() == 3:
-        B, C, L = x.shape
-        x = x.reshape(B, C, 1, L)
+        x = _tok4(x)
     return K.groupnorm_stats(x, norm.num_groups, norm.eps, norm.weight, norm.bias, scale, shift)
 
 
@@ -52,13 +60,13 @@ class PointwiseConv1d(nn.Conv1d):
         super().__init__(in_channels, out_channels, 1)
         self._packed = K.PackedConv()
 
-    def forward(self, x, res=None, out=None, gn_coeffs=None, gn_silu=False):
+    def forward(self, x, res=None, out=None, gn_coeffs=None, gn_silu=False, emit_stats=False):
         B, C, L = x.shape
-        r4 = None if res is None else res.reshape(B, -1, 1, L)
-        o4 = None if out is None else out.view(B, -1, 1, L)
-        y = K.conv2d_ring(x.reshape(B, C, 1, L), self._packed, self.weight, self.bias, res=r4,
-                          out=o4, gn_coeffs=gn_coeffs, gn_silu=gn_silu)
-        return y.view(B, -1, L)
+        r4 = None if res is None else _tok4(res)
+        o4 = None if out is None else _tok4(out)
+        y = K.conv2d_ring(_tok4(x), self._packed, self.weight, self.bias, res=r4,
+                          out=o4, gn_coeffs=gn_coeffs, gn_silu=gn_silu, emit_stats=emit_stats)
+        return K.alias(y.view(B, -1, L), y)
 
 
 def conv_nd(dims, *args, **kwargs):

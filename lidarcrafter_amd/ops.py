@@ -167,14 +167,46 @@ class _OctStatsHandle:
         self.buf, self.channels, self.slots, self.shape = buf, channels, slots, shape
 
 
+def _dense_plane(t: torch.Tensor) -> bool:
+    H, W = t.shape[2], t.shape[3]
+    st = t.stride()
+    return (W == 1 or st[3] == 1) and (H == 1 or st[2] == W) and st[1] == H * W
+
+
+def alias(view: torch.Tensor, src: torch.Tensor, c0: int = 0) -> torch.Tensor:
+    """Declare `view` an alias of channels [c0, ...) of `src` (same memory; the plane may be re-indexed,
+    e.g. [B,C,H,W] <-> [B,C,1,H*W] <-> [B,C,H*W]) so that producer statistics follow it.  Needed
+    because torch.inference_mode (the samplers) does not record `_base` on views; a no-op for
+    correctness otherwise.  Returns `view`."""
+    own, b0 = _stats_owner(src)
+    if own is not None:
+        view._lc_owner = (own, b0 + c0)
+    return view
+
+
+def chan_slice(buf: torch.Tensor, c0: int, c1: int) -> torch.Tensor:
+    """buf[:, c0:c1] of a [B,C,H,W] buffer, statistics bookkept on `buf` in every grad mode."""
+    return alias(buf[:, c0:c1], buf, c0)
+
+
 def _stats_owner(t: torch.Tensor):
     """(owner tensor object, first channel of `t` inside it), or (None, 0) when `t` is not a plain
     channel slice of its base."""
+    o = getattr(t, "_lc_owner", None)
+    if o is not None:
+        return o
+    if t.dim() != 4:
+        return None, 0
     base = t._base
     if base is None:
         return t, 0
-    if base.dim() != 4 or t.dim() != 4 or base.stride() != t.stride() or \
-            base.shape[0] != t.shape[0] or base.shape[2:] != t.shape[2:]:
+    # a channel slice, possibly with the plane re-indexed ([B,C,H,W] <-> [B,C,1,H*W] token views of the
+    # attention blocks): the statistics are sums over the pixels of a channel octet, whatever the
+    # plane's shape -- what must agree are the batch / channel strides and the (dense) plane size
+    if base.dim() != 4 or t.dim() != 4 or base.shape[0] != t.shape[0] or \
+            base.stride()[:2] != t.stride()[:2] or \
+            base.shape[2] * base.shape[3] != t.shape[2] * t.shape[3] or \
+            not _dense_plane(base) or not _dense_plane(t):
         return None, 0
     off = t.storage_offset() - base.storage_offset()
     if off < 0 or off % base.stride(1):
@@ -208,7 +240,17 @@ def _attach_stats(out: torch.Tensor, h: _OctStatsHandle) -> None:
     d[(c0, out.shape[1])] = h
 
 
+GN_TRACE = None   # developer aid: a collections.Counter of (shape, G, found) per statistics lookup
+
+
 def _find_stats(x: torch.Tensor, G: int):
+    r = _find_stats_impl(x, G)
+    if GN_TRACE is not None:
+        GN_TRACE[(tuple(x.shape), G, r is not None)] += 1
+    return r
+
+
+def _find_stats_impl(x: torch.Tensor, G: int):
     """Handles covering all channels of x with at most two segments (each a whole number of
     groups, groups whole octets), or None."""
     if x.dim() != 4:
@@ -222,7 +264,7 @@ def _find_stats(x: torch.Tensor, G: int):
     C = x.shape[1]
     if C % G or (C // G) % 8:
         return None
-    shape = (x.shape[0], x.shape[2], x.shape[3])
+    shape = (x.shape[0], x.shape[2] * x.shape[3])
     h = d.get((c0, C))
     if h is not None and h.shape == shape:
         return (h,)
@@ -698,7 +740,7 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                                                  packed.range_ptr(x.device), _stream()),
                   "lc_conv2d_ring_f16x2_fwd")
             if sbuf is not None:
-                _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H, W)))
+                _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H * W)))
         else:
             check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res),
                                            r_bs, out.data_ptr(), y_bs, B, Ci, Co, H, W, ks,
@@ -763,7 +805,7 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                                                     packed.range_ptr(dev), _stream()),
                   "lc_conv2d_ring_f16x2_ps_fwd")
         if sbuf is not None:
-            _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H, W)))
+            _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H * W)))
     return out
 
 

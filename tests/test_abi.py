@@ -114,8 +114,8 @@ def test_producer_stats_bookkeeping():
     B, H, W = 2, 4, 8
     buf = torch.zeros(B, 128, H, W)
     lo, hi = buf[:, :64], buf[:, 64:]
-    h0 = K._OctStatsHandle(torch.zeros(1), 64, 3, (B, H, W))
-    h1 = K._OctStatsHandle(torch.zeros(1), 64, 5, (B, H, W))
+    h0 = K._OctStatsHandle(torch.zeros(1), 64, 3, (B, H * W))
+    h1 = K._OctStatsHandle(torch.zeros(1), 64, 5, (B, H * W))
     K._attach_stats(lo, h0)
     assert K._find_stats(buf, 8) is None                       # second half unknown
     K._attach_stats(hi, h1)
@@ -140,6 +140,24 @@ def test_producer_stats_bookkeeping():
     assert K._find_stats(own, 8) == (h0,)
     K._drop_stats(own)
     assert K._find_stats(own, 8) is None
+    # the plane may be re-indexed (token views of the attention blocks): same sums
+    K._attach_stats(own, h0)
+    assert K._find_stats(own.view(B, 64, 1, H * W), 8) == (h0,)
+    # torch.inference_mode (the samplers) records no `_base`: slices / token views made through
+    # ops.chan_slice / ops.alias keep the bookkeeping on the buffer they belong to
+    with torch.inference_mode():
+        cat = torch.zeros(B, 128, H, W)
+        assert cat[:, 64:]._base is None
+        K._attach_stats(K.chan_slice(cat, 0, 64), h0)
+        hi2 = K.chan_slice(cat, 64, 128)
+        K._attach_stats(hi2, h1)
+        assert K._find_stats(cat, 8) == (h0, h1)
+        tok = K.alias(torch.as_strided(hi2, (B, 64, H * W), (hi2.stride(0), H * W, 1)), hi2)
+        tok4 = K.alias(torch.as_strided(tok, (B, 64, 1, H * W), (tok.stride(0), H * W, H * W, 1)), tok)
+        assert K._find_stats(tok4, 8) == (h1,)
+        K._drop_stats(K.chan_slice(cat, 64, 128))               # a writer into that range
+        assert K._find_stats(tok4, 8) is None and K._find_stats(cat, 8) is None
+        assert K._find_stats(K.chan_slice(cat, 0, 64), 8) == (h0,)
 
 
 def test_bench_line_contract():
