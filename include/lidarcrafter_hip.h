@@ -95,8 +95,11 @@ int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t n, lc_conv
 /* Producer-side GroupNorm statistics of one channel segment: the entries a conv wrote through
  * gn_ostats_out (below), consumed by lc_groupnorm_apply_os or by the next conv's fused input norm. */
 typedef struct lc_oct_stats {
-    const float* p;     /* [B, channels/8, slots, 4] */
+    const float* p;     /* [B, channels/unit, slots, 4] */
     int channels, slots;
+    int unit;           /* channels per entry: 8 (octets), or 2 (pairs: lc_conv2d_ring_f16x2_fwd with
+                           gn_ostats_unit = 2, for a GroupNorm with 2 / 4 / 6 channels per group; accepted
+                           by the conv's fused input norm, LC_EUNSUP in lc_groupnorm_apply_os*) */
 } lc_oct_stats;
 /* Input normalisation straight from the statistics (no lc_groupnorm_coeffs launch): the partials
  * of lc_groupnorm_stats over the conv's input plus the GroupNorm / AdaGN parameters; every block
@@ -121,7 +124,8 @@ int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, co
                              const float* gn_coeffs /* NULL or [B, gn_cpad, 4] */, int gn_cpad,
                              int gn_silu, const lc_gn_stats_input* gn_stats /* NULL, or instead of
                              gn_coeffs */,
-                             float* gn_ostats_out /* NULL or [B, Co/8, slots, 4], see below */,
+                             float* gn_ostats_out /* NULL or [B, Co/unit, slots, 4], see below */,
+                             int gn_ostats_unit /* 8 (octet entries) or 2 (pair entries, lc_oct_stats) */,
                              const float* wmeta /* from lc_pack_conv_weight_f16x2 */,
                              lc_conv_range* range /* this layer's input range state */,
                              lc_stream_t s);

@@ -20,7 +20,7 @@ _op = C.POINTER(CmOperand)
 
 class OctStats(C.Structure):
     """struct lc_oct_stats: producer-side GroupNorm statistics of one channel segment."""
-    _fields_ = [("p", vp), ("channels", i32), ("slots", i32)]
+    _fields_ = [("p", vp), ("channels", i32), ("slots", i32), ("unit", i32)]
 
 
 _os = C.POINTER(OctStats)
@@ -51,7 +51,7 @@ SIGNATURES = {
     "lc_packed_conv_weight_f16x2_elems": (i64, [i32, i32, i32]),
     "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "lc_conv2d_ring_f16x2_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
-                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp, vp, vp, vp]),
+                                       i32, i32, f32, i32, vp, i32, i32, _gs, vp, i32, vp, vp, vp]),
     "lc_split_act_units": (i64, [i32, i32, i32, i32]),
     "lc_groupnorm_apply_split": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32,
                                        f32, i32, vp, vp]),

@@ -114,7 +114,7 @@ struct ConvArgsH {
     lc_gn_stats_input gs;     // (os0 / os1 are host pointers: the kernels read seg[] instead)
     // ... or the octet statistics the input's producer(s) emitted (gs.partials == NULL):
     // seg[0] covers channels [0, seg[0].channels), seg[1] the rest
-    struct OctSeg { const f32x4* p; int channels, slots; } seg[2];
+    struct OctSeg { const f32x4* p; int channels, slots, ush; } seg[2];   // ush: log2(channels per entry) = 3 or 1
     int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles of one sample
     int vert;  // 1: the block walks its tpb tiles down H (W-neighbours run concurrently), 0: along W
     int xcd;   // 1: blockIdx.x is remapped so that each XCD owns a contiguous range of tiles
@@ -122,8 +122,10 @@ struct ConvArgsH {
     // per sample, channel octet (8 consecutive channels) and wave tile one entry
     // (pivot, n, sum(y - pivot), sum((y - pivot)^2));  ostats[(b*Co/8 + octet)*oslots + slot],
     // slot = (tile_row*tiles_w + tile_col)*WPX + wave_px.  Pipelined kernel only.
+    // ounit = 2: one entry per channel PAIR instead (ostats[(b*Co/2 + pair)*oslots + slot]) -- for a consumer
+    // GroupNorm with 2 / 4 / 6 channels per group (GroupNorm32 at 64 ... 192 channels); deferred epilogue only.
     f32x4* ostats;
-    int oslots;
+    int oslots, ounit;
 };
 
 constexpr int GN_MAX_C = 1024;   // LDS table of fused GroupNorm rows: 16 KB
@@ -181,10 +183,11 @@ __device__ __forceinline__ void gn_rows_from_ostats(const ConvArgsH& a, int b, i
         const int cg0 = g * cpg;
         const bool s1 = cg0 >= a.seg[0].channels;
         const int slots = s1 ? a.seg[1].slots : a.seg[0].slots;
+        const int ush = s1 ? a.seg[1].ush : a.seg[0].ush;
         const f32x4* e =
-            s1 ? a.seg[1].p + ((long long)b * (a.seg[1].channels >> 3) + ((cg0 - a.seg[0].channels) >> 3)) * slots
-               : a.seg[0].p + ((long long)b * (a.seg[0].channels >> 3) + (cg0 >> 3)) * slots;
-        const int n_ent = (cpg >> 3) * slots;
+            s1 ? a.seg[1].p + ((long long)b * (a.seg[1].channels >> ush) + ((cg0 - a.seg[0].channels) >> ush)) * slots
+               : a.seg[0].p + ((long long)b * (a.seg[0].channels >> ush) + (cg0 >> ush)) * slots;
+        const int n_ent = (cpg >> ush) * slots;
         const double P0 = (double)e[0].x;
         double N = 0.0, S = 0.0, Q = 0.0;
         for (int base = lane; base < n_ent; base += 64 * 16) {   // 16 loads in flight per lane
@@ -560,6 +563,16 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// the same without the last step: lanes 31 / 63 hold the sums of lanes 0-31 / 32-63
+__device__ __forceinline__ float half_sum_to_lane31_63(float v) {
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);
+    return v;
+}
+
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (descriptor + per-lane voffset + uniform
 // soffset; out of range -> zeros) -> LDS at dst + 16 * lane.  (The builtin exists in the device
 // pass only; the host pass needs just the kernel's stub.)
@@ -601,8 +614,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // when there is none -> zeros): out-of-image pixels, ragged channel tails and "no previous tile"
 // are an out-of-range offset, so the per-value code has no branch and stays in the MFMAs' basic
 // block.
-template <class C, bool EMIT>
-struct DefEpi {
+template <class C, int EMIT>   // 0: no statistics, 1: octet entries, 2: pair entries (compile time: a runtime
+struct DefEpi {                // branch here split the MFMAs' basic block -- level-0 launch 84 -> 100 us)
     static constexpr int TCO = C::TCO_, TPX = C::TPX_, NTAP = C::NTAP;
     static constexpr int NV = TCO * TPX * 16;              // values per thread and tile
     static constexpr int DCH = 4;                          // chunks of the next tile carrying deferred work
@@ -623,29 +636,34 @@ struct DefEpi {
 
     f32x16 accp[TCO][TPX];
     float rq[RING];
-    float st_p, st_s, st_q;    // the running octet: pivot, sum (v - p), sum (v - p)^2
+    float st_p, st_s, st_q;    // the running octet: pivot, sum (v - p), sum (v - p)^2 of channels q = 0, 1 of each quad
+    float st_s2, st_q2;        // pair entries: ... and of channels q = 2, 3 (unused for octet entries)
+    f32x4 ent0, ent1;          // pair entries: the two entries of the last octet (see finalize_with)
+    static constexpr bool pairs = EMIT == 2;   // entries per channel pair (ConvArgsH::ounit == 2)
     unsigned voff[TPX];        // byte offset of (channel co_wave, pixel j) in the sample; OOB = nothing to do
     __amdgpu_buffer_rsrc_t rs_y, rs_r, rs_o;
     float out_unscale, out_scale;
     unsigned HW4;              // bytes per channel plane
     int co_wave, Co;
-    float nv8;                 // 8 x valid pixels of the parked tile (entry field)
-    unsigned ent_off;          // byte offset of the parked tile's entry of octet 0 of this wave (lane 63), or OOB
-    unsigned oct_stride;       // bytes between the entries of consecutive octets
+    float nv8;                 // (channels per entry) x valid pixels of the parked tile (entry field)
+    unsigned ent_off;          // byte offset of the parked tile's entry of this lane's first unit (octets: lane 63;
+                               // pairs: lanes 31 / 63 = channel quads 0 / 1 of the octet), or OOB
+    unsigned oct_stride;       // bytes between the entries of consecutive units (octets or pairs)
 
     __device__ __forceinline__ void init(float* yb, const float* rb, int Co_, int HW, float unscale,
-                                         float oscale, int co_wave_, f32x4* ostats_b, int oslots) {
+                                         float oscale, int co_wave_, f32x4* ostats_b, int oslots, int ounit) {
         const unsigned bytes = (unsigned)Co_ * (unsigned)HW * 4u;
         rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, bytes, 0x00020000);
         rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rb, 0, rb ? bytes : 0u, 0x00020000);
         rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)ostats_b, 0,
-                                                 ostats_b ? (unsigned)(Co_ >> 3) * (unsigned)oslots * 16u : 0u,
+                                                 ostats_b ? (unsigned)(Co_ >> (pairs ? 1 : 3)) * (unsigned)oslots * 16u : 0u,
                                                  0x00020000);
         out_unscale = unscale; out_scale = oscale; HW4 = (unsigned)HW * 4u;
         co_wave = co_wave_; Co = Co_;
         oct_stride = (unsigned)oslots * 16u;
         nv8 = 0.f; ent_off = OOB;
-        st_p = st_s = st_q = 0.f;
+        st_p = st_s = st_q = st_s2 = st_q2 = 0.f;
+        ent0 = ent1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TPX; ++j) voff[j] = OOB;
 #pragma unroll
@@ -680,20 +698,35 @@ struct DefEpi {
             const bool pok = voff[j] != OOB;
             if (k % OCTV == 0) {
                 st_p = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0);
-                st_s = 0.f; st_q = 0.f;
+                st_s = 0.f; st_q = 0.f; st_s2 = 0.f; st_q2 = 0.f;
             }
             const float d = pok ? v - st_p : 0.0f;
-            st_s += d;
-            st_q = fmaf(d, d, st_q);
-            if (k % OCTV == OCTV - 1) {                  // the octet is complete: one entry from lane 63
-                const float s_ = wave_sum_to_lane63(st_s);
-                const float q_ = wave_sum_to_lane63(st_q);
+            if (pairs && (k & 2)) { st_s2 += d; st_q2 = fmaf(d, d, st_q2); }   // (k & 3 = channel inside the lane's quad)
+            else { st_s += d; st_q = fmaf(d, d, st_q); }
+            if (k % OCTV == OCTV - 1) {                  // the octet is complete
+                typedef __attribute__((ext_vector_type(4))) unsigned u4;
                 const int oct = i * 4 + m;               // octet index inside this wave's channel rows
                 const bool ok = ent_off != OOB && co_wave + i * 32 + 8 * m < Co;   // (co_wave carries 4 * kh <= 4)
-                const f32x4 e = {st_p, nv8, s_, q_};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, e),
-                                                       rs_o, ok ? ent_off : OOB, (unsigned)oct * oct_stride, 0);
+                if constexpr (!pairs) {                  // one entry from lane 63
+                    const f32x4 e = {st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e), rs_o, ok ? ent_off : OOB,
+                                                           (unsigned)oct * oct_stride, 0);
+                } else {                                 // pairs (8m + 4kh + 0,1) and (+ 2,3) from lanes 31 / 63
+                    ent0 = f32x4{st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q)};
+                    ent1 = f32x4{st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2)};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ent0), rs_o, ok ? ent_off : OOB,
+                                                           (unsigned)(4 * oct) * oct_stride, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ent1), rs_o, ok ? ent_off : OOB,
+                                                           (unsigned)(4 * oct + 1) * oct_stride, 0);
+                }
             }
+            // Pair entries only: the two entries live in registers of their own for the whole tile loop
+            // (the "+v" below makes them live and 'modified' at every value).  Without it hipcc reused an
+            // entry's data registers right behind its buffer_store_dwordx4 (e.g. as the destination of a
+            // ds_read_b128 two instructions later) and stored entries sporadically carried foreign data in
+            // one dword -- 8-wave tiles only, where the store waits in a saturated memory pipeline
+            // (profiles/r03_conv_phases.txt, "pair entries").
+            if constexpr (pairs) asm volatile("" : "+v"(ent0), "+v"(ent1));
         }
     }
     // slot s of the deferred stream (s static after unrolling)
@@ -713,7 +746,7 @@ struct DefEpi {
             n += ((s + LAG) * VPT + u < NV) ? 1 : 0;
             const int k = s * VPT + u;
             n += (k < NV) ? 1 : 0;
-            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? 1 : 0;
+            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) : 0;
         }
         return n;
     }
@@ -754,8 +787,13 @@ struct DefEpi {
         }
         if constexpr (EMIT) {
             const int slot_id = ((h0 / C::TH_) * tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
-            nv8 = (float)(8 * nvalid);
-            ent_off = lane == 63 ? (unsigned)(co_blk >> 3) * oct_stride + (unsigned)slot_id * 16u : OOB;
+            if constexpr (!pairs) {
+                nv8 = (float)(8 * nvalid);
+                ent_off = lane == 63 ? (unsigned)(co_blk >> 3) * oct_stride + (unsigned)slot_id * 16u : OOB;
+            } else {
+                nv8 = (float)(2 * nvalid);
+                ent_off = l31 == 31 ? (unsigned)((co_blk >> 1) + 2 * (lane >> 5)) * oct_stride + (unsigned)slot_id * 16u : OOB;
+            }
         }
         if (prefetch) {                                 // (the last tile is drained with its own loads)
 #pragma unroll
@@ -770,7 +808,7 @@ struct DefEpi {
 // as the MFMAs (as a runtime branch it formed its own block, with every LDS latency of the row
 // reads exposed and no MFMA issued meanwhile -- measured r02r: 64->64 @8x32x1024 103 us, 76 us
 // with the staging arithmetic removed).
-template <class C, bool EMIT_STATS, int GNM>
+template <class C, int EMIT_STATS, int GNM>
 __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(ConvArgsH a) {
     constexpr int CB = C::CB, HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
     constexpr int XR = C::XR, XW = C::XW, XU = C::XU, WU = C::WU, NWU = C::NWU;
@@ -1130,7 +1168,8 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
     float* yb = a.y + (long long)b * a.y_bs;
     const float* rb = (a.res && !(LC_ABLATE & 16)) ? a.res + (long long)b * a.res_bs : nullptr;
     de.init(yb, rb, a.Co, HW, out_unscale, a.out_scale, co_wave,
-            a.ostats ? a.ostats + (long long)b * (a.Co >> 3) * a.oslots : nullptr, a.oslots);
+            a.ostats ? a.ostats + (long long)b * (a.Co >> (a.ounit == 2 ? 1 : 3)) * a.oslots : nullptr, a.oslots,
+            a.ounit);
     acc_init();
 #if LC_TIMING
     unsigned long long t_comp = 0, t_bar = 0, t_epi = 0, n_chunk = 0;
@@ -1593,10 +1632,16 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     }
     const int gnm = a.gn ? (a.gn_silu ? 1 : 2) : 0;
 #define LC_PIPE_LAUNCH(E, G) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, E, G>), grid, dim3(C::NT), 0, st, a)
-    if (a.ostats) {
-        if (gnm == 1) LC_PIPE_LAUNCH(true, 1); else if (gnm == 2) LC_PIPE_LAUNCH(true, 2); else LC_PIPE_LAUNCH(true, 0);
+    if (a.ostats && a.ounit == 2) {                    // pair entries: 3x3 only
+        if constexpr (C::NTAP == 9) {
+            if (gnm == 1) LC_PIPE_LAUNCH(2, 1); else if (gnm == 2) LC_PIPE_LAUNCH(2, 2); else LC_PIPE_LAUNCH(2, 0);
+        } else {
+            return LC_EUNSUP;
+        }
+    } else if (a.ostats) {
+        if (gnm == 1) LC_PIPE_LAUNCH(1, 1); else if (gnm == 2) LC_PIPE_LAUNCH(1, 2); else LC_PIPE_LAUNCH(1, 0);
     } else {
-        if (gnm == 1) LC_PIPE_LAUNCH(false, 1); else if (gnm == 2) LC_PIPE_LAUNCH(false, 2); else LC_PIPE_LAUNCH(false, 0);
+        if (gnm == 1) LC_PIPE_LAUNCH(0, 1); else if (gnm == 2) LC_PIPE_LAUNCH(0, 2); else LC_PIPE_LAUNCH(0, 0);
     }
 #undef LC_PIPE_LAUNCH
     return lc_launch_status();
@@ -1827,7 +1872,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
                                         int64_t res_bs, float* y, int64_t y_bs, int B, int Ci,
                                         int Co, int H, int W, int ks, float out_scale, int tile_cfg,
                                         const float* gn_coeffs, int gn_cpad, int gn_silu,
-                                        const lc_gn_stats_input* gn_stats, float* gn_ostats_out,
+                                        const lc_gn_stats_input* gn_stats, float* gn_ostats_out, int gn_ostats_unit,
                                         const float* wmeta, lc_conv_range* range, lc_stream_t s) {
     if (!x || !wp_hi || !wp_lo || !y || !wmeta || !range || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 ||
         W <= 0)
@@ -1846,7 +1891,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.gn = reinterpret_cast<const f32x4*>(gn_coeffs);
     a.Cgn = gn_cpad; a.gn_silu = gn_silu;
     a.gs = lc_gn_stats_input{nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-    a.seg[0] = a.seg[1] = ConvArgsH::OctSeg{nullptr, 0, 0};
+    a.seg[0] = a.seg[1] = ConvArgsH::OctSeg{nullptr, 0, 0, 3};
     if (gn_stats) {
         if (gn_coeffs || gn_stats->G <= 0 || Ci % gn_stats->G) return LC_EINVAL;
         if (gn_stats->partials) {
@@ -1856,9 +1901,11 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
             if (!s0 || !s0->p || s0->channels <= 0 || s0->slots <= 0) return LC_EINVAL;
             if (s1 && (!s1->p || s1->channels <= 0 || s1->slots <= 0)) return LC_EINVAL;
             const int c0 = s0->channels, c1 = s1 ? s1->channels : 0, cpg = Ci / gn_stats->G;
-            if (c0 + c1 != Ci || cpg % 8 || c0 % cpg || gn_stats->G > GN_MAX_G) return LC_EUNSUP;
-            a.seg[0] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s0->p), c0, s0->slots};
-            if (s1) a.seg[1] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s1->p), c1, s1->slots};
+            const int u0 = s0->unit, u1 = s1 ? s1->unit : u0;
+            if ((u0 != 8 && u0 != 2) || (u1 != 8 && u1 != 2)) return LC_EINVAL;
+            if (c0 + c1 != Ci || cpg % u0 || cpg % u1 || c0 % cpg || gn_stats->G > GN_MAX_G) return LC_EUNSUP;
+            a.seg[0] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s0->p), c0, s0->slots, u0 == 8 ? 3 : 1};
+            if (s1) a.seg[1] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s1->p), c1, s1->slots, u1 == 8 ? 3 : 1};
         }
         a.gs = *gn_stats;
         a.gs.os0 = a.gs.os1 = nullptr;
@@ -1876,11 +1923,13 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
         a.W = W = 64;
     }
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
-    a.ostats = nullptr; a.oslots = 0;
+    a.ostats = nullptr; a.oslots = 0; a.ounit = 8;
     if (gn_ostats_out) {
+        if (gn_ostats_unit != 8 && gn_ostats_unit != 2) return LC_EINVAL;
         a.oslots = pipe_stat_slots(tile_cfg, H, W);
         if (a.oslots <= 0 || Co % 8) return LC_EUNSUP;     // ask lc_conv2d_ring_f16x2_stats_slots first
         a.ostats = reinterpret_cast<f32x4*>(gn_ostats_out);
+        a.ounit = gn_ostats_unit;
     }
     return ks == 3 ? dispatch_h<3>(tile_cfg, a, lc_s(s)) : dispatch_h<1>(tile_cfg, a, lc_s(s));
 }
@@ -1930,13 +1979,13 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
     a.tiles_h = a.tiles_w = 0;
     a.gn = nullptr; a.Cgn = 0; a.gn_silu = 0;
     a.gs = lc_gn_stats_input{nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-    a.seg[0] = a.seg[1] = ConvArgsH::OctSeg{nullptr, 0, 0};
+    a.seg[0] = a.seg[1] = ConvArgsH::OctSeg{nullptr, 0, 0, 3};
     a.tpb = 0;
     if (tile_cfg >= 100) { a.tpb = tile_cfg / 100; tile_cfg %= 100; }
     // (the pipelined tile shapes only: the heuristic's Ci >= 24 branch)
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci < 24 ? 24 : Ci, Co, H, W, 3);
     if (pipe_stat_slots(tile_cfg, H, W) <= 0) return LC_EUNSUP;
-    a.ostats = nullptr; a.oslots = 0;
+    a.ostats = nullptr; a.oslots = 0; a.ounit = 8;
     if (gn_ostats_out && !splitk_part) {
         a.oslots = pipe_stat_slots(tile_cfg, H, W);
         if (Co % 8) return LC_EUNSUP;

@@ -531,6 +531,7 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
                                      int act_silu, lc_stream_t s) {
     if (!x || !y || B <= 0 || G <= 0 || C % G || !s0 || !s0->p || s0->channels <= 0 || s0->slots <= 0)
         return LC_EINVAL;
+    if (s0->unit != 8 || (s1 && s1->unit != 8)) return LC_EUNSUP;   // pair entries: fused conv input norm only
     OctStats2 os;
     os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
     os.p1 = nullptr; os.c1 = 0; os.slots1 = 0;
@@ -600,6 +601,7 @@ extern "C" int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const l
     if (!x || !y_split || !range || B <= 0 || G <= 0 || C % G || !s0 || !s0->p || s0->channels <= 0 ||
         s0->slots <= 0)
         return LC_EINVAL;
+    if (s0->unit != 8 || (s1 && s1->unit != 8)) return LC_EUNSUP;
     OctStats2 os;
     os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
     os.p1 = nullptr; os.c1 = 0; os.slots1 = 0;

@@ -17,6 +17,7 @@ LayoutUnetV1 :599-902) for the configuration every shipped layout config uses
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch as th
@@ -31,6 +32,15 @@ from .nn import SiLU, conv_nd, conv_nd_range, gn32_coeffs, linear, normalization
 
 class TimestepBlock(nn.Module):
     """Any module whose forward takes the timestep embedding as a second argument."""
+
+
+PAIR_STATS = os.environ.get("LC_GN_PAIR_STATS", "1") != "0"   # developer switch (A/B of the pair entries)
+
+
+def _stats_unit(channels: int):
+    """`emit_stats` of a conv whose output feeds a GroupNorm32: octet entries when the 32 groups are
+    whole octets (>= 256 channels), pair entries below (64 / 128 channels: 2 / 4 per group)."""
+    return True if (channels // 32) % 8 == 0 or not PAIR_STATS else 2
 
 
 class ResBlock(TimestepBlock):
@@ -74,28 +84,29 @@ class ResBlock(TimestepBlock):
     def forward(self, x, emb=None, scale_shift=None, out=None):
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
         fuse = K.fuse_gn(self.out_channels)
+        su = _stats_unit(self.out_channels)
         if self.updown:      # GN -> SiLU -> resample -> conv: the norm cannot ride on the conv
             a = self.op(self.in_layers[0](x, act_silu=True))
             x = self.op(x)
-            h = self.in_layers[2](a, emit_stats=True)
+            h = self.in_layers[2](a, emit_stats=su)
         elif fuse:
             a = None
-            h = self.in_layers[2](x, gn_coeffs=gn32_coeffs(self.in_layers[0], x), emit_stats=True)
+            h = self.in_layers[2](x, gn_coeffs=gn32_coeffs(self.in_layers[0], x), emit_stats=su)
         else:
             a = self.in_layers[0](x, act_silu=True, split_for=self.in_layers[2]._packed)
-            h = self.in_layers[2](a, emit_stats=True)   # statistics for out_layers[0]
+            h = self.in_layers[2](a, emit_stats=su)   # statistics for out_layers[0]
             if isinstance(a, K.SplitAct):
                 a = None
         if fuse:
             sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x)
-            return self.out_layers[3](h, res=sk, out=out, emit_stats=True,
+            return self.out_layers[3](h, res=sk, out=out, emit_stats=su,
                                       gn_coeffs=gn32_coeffs(self.out_layers[0], h, scale, shift))
         reuse = a if a is not None and a.shape == h.shape and not K.can_presplit(
             self.out_channels, self.out_layers[0].num_groups) else None
         a2 = self.out_layers[0](h, scale, shift, act_silu=True, out=reuse,
                                 split_for=self.out_layers[3]._packed)
         sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
-        return self.out_layers[3](a2, res=sk, out=out, emit_stats=True)   # ... for the next block's norm
+        return self.out_layers[3](a2, res=sk, out=out, emit_stats=su)   # ... for the next block's norm
 
 
 class ObjectAwareCrossAttention(nn.Module):
@@ -197,6 +208,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 x = layer(x, emb, scale_shift=ss, out=o)
             elif isinstance(layer, ObjectAwareCrossAttention):
                 x, _ = layer(x, cond_kwargs, out=o)
+            elif isinstance(layer, ops.Conv2d):      # the input convolution feeds the first block's norm
+                x = layer(x, out=o, emit_stats=_stats_unit(layer.out_channels))
             else:
                 x = layer(x, out=o)
         return x, None

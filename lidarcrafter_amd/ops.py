@@ -161,10 +161,10 @@ PRODUCER_GN_STATS = _os.environ.get("LC_GN_PRODUCER_STATS", "1") != "0"
 
 
 class _OctStatsHandle:
-    __slots__ = ("buf", "channels", "slots", "shape")
+    __slots__ = ("buf", "channels", "slots", "shape", "unit")
 
-    def __init__(self, buf, channels, slots, shape):
-        self.buf, self.channels, self.slots, self.shape = buf, channels, slots, shape
+    def __init__(self, buf, channels, slots, shape, unit=8):
+        self.buf, self.channels, self.slots, self.shape, self.unit = buf, channels, slots, shape, unit
 
 
 def _dense_plane(t: torch.Tensor) -> bool:
@@ -243,14 +243,16 @@ def _attach_stats(out: torch.Tensor, h: _OctStatsHandle) -> None:
 GN_TRACE = None   # developer aid: a collections.Counter of (shape, G, found) per statistics lookup
 
 
-def _find_stats(x: torch.Tensor, G: int):
-    r = _find_stats_impl(x, G)
+def _find_stats(x: torch.Tensor, G: int, pairs_ok: bool = False):
+    """pairs_ok: the consumer can fold pair entries (the conv's fused input norm); the apply kernels
+    take octet entries only."""
+    r = _find_stats_impl(x, G, pairs_ok)
     if GN_TRACE is not None:
         GN_TRACE[(tuple(x.shape), G, r is not None)] += 1
     return r
 
 
-def _find_stats_impl(x: torch.Tensor, G: int):
+def _find_stats_impl(x: torch.Tensor, G: int, pairs_ok: bool = False):
     """Handles covering all channels of x with at most two segments (each a whole number of
     groups, groups whole octets), or None."""
     if x.dim() != 4:
@@ -262,16 +264,21 @@ def _find_stats_impl(x: torch.Tensor, G: int):
     if not d:
         return None
     C = x.shape[1]
-    if C % G or (C // G) % 8:
+    if C % G:
         return None
+    cpg = C // G
+
+    def usable(h):
+        return h.shape == shape and cpg % h.unit == 0 and (h.unit == 8 or pairs_ok)
+
     shape = (x.shape[0], x.shape[2] * x.shape[3])
     h = d.get((c0, C))
-    if h is not None and h.shape == shape:
+    if h is not None and usable(h):
         return (h,)
     for (k0, kc), h0 in d.items():
-        if k0 == c0 and kc < C and kc % (C // G) == 0:
+        if k0 == c0 and kc < C and kc % cpg == 0:
             h1 = d.get((c0 + kc, C - kc))
-            if h1 is not None and h0.shape == shape and h1.shape == shape:
+            if h1 is not None and usable(h0) and usable(h1):
                 return (h0, h1)
     return None
 
@@ -678,7 +685,8 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     (from `groupnorm_coeffs`) is given -- x' = silu?(GroupNorm(x)) applied on the fly while the
     input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference.
 
-    emit_stats: the conv also leaves per-octet GroupNorm statistics of what it stores, attached to
+    emit_stats: True / 8 = the conv also leaves per-octet GroupNorm statistics of what it stores (2 =
+    per channel pair, for a consumer GroupNorm with 2 / 4 / 6 channels per group), attached to
     the output tensor object; a following `groupnorm` / `groupnorm_stats` of that tensor (or of a
     concat buffer whose halves both carry them) then skips its statistics pass.  Every wrapper of
     this module that writes into an `out=` tensor forgets the statistics of what it overwrites;
@@ -728,19 +736,20 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                     raise ValueError("gn_coeffs must be contiguous [B, Cpad, 4]")
                 cpad = gn_coeffs.shape[1]
             sbuf, slots = None, 0
-            if emit_stats and PRODUCER_GN_STATS:
+            unit = 2 if (emit_stats is not True and int(emit_stats) == 2) else 8
+            if emit_stats and PRODUCER_GN_STATS and (unit == 8 or ks == 3):   # pair entries: 3x3 kernels only
                 slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, Ci, Co, H, W, ks, int(tile_cfg)))
                 if slots > 0:
-                    sbuf = torch.empty((B, Co // 8, slots, 4), device=x.device, dtype=_F32)
+                    sbuf = torch.empty((B, Co // unit, slots, 4), device=x.device, dtype=_F32)
             check(lib().lc_conv2d_ring_f16x2_fwd(x.data_ptr(), x_bs, wh.data_ptr(), wl.data_ptr(),
                                                  _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                  Ci, Co, H, W, ks, float(out_scale),
                                                  int(tile_cfg), _p(gn_coeffs), cpad, int(gn_silu),
-                                                 gs_ref, _p(sbuf), packed.wmeta.data_ptr(),
+                                                 gs_ref, _p(sbuf), unit, packed.wmeta.data_ptr(),
                                                  packed.range_ptr(x.device), _stream()),
                   "lc_conv2d_ring_f16x2_fwd")
             if sbuf is not None:
-                _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H * W)))
+                _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H * W), unit))
         else:
             check(lib().lc_conv2d_ring_fwd(x.data_ptr(), x_bs, wp.data_ptr(), _p(bias), _p(res),
                                            r_bs, out.data_ptr(), y_bs, B, Ci, Co, H, W, ks,
@@ -777,7 +786,9 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
     ks = splitk_factor(B, Ci, Co, H, W) if tile_cfg == 0 else 0
     with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9):
         sbuf, slots = None, 0
-        want_stats = emit_stats and PRODUCER_GN_STATS and Co % 8 == 0
+        # (pair entries -- emit_stats == 2 -- come from the fp32-input kernel's deferred epilogue only)
+        want_stats = emit_stats and (emit_stats is True or int(emit_stats) == 8) and PRODUCER_GN_STATS and \
+            Co % 8 == 0
         if ks >= 2:
             # small grid: ksplit blocks per tile over disjoint K ranges + one deterministic reduce
             part = torch.empty((ks, B, Co, H, W), device=dev, dtype=_F32)
@@ -877,7 +888,7 @@ def groupnorm(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, scale=
         import ctypes as C_
         from ._lib import OctStats
 
-        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots) for h in hs]
+        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots, h.unit) for h in hs]
         with _Timed("groupnorm", 8.0 * B * C * H * W):
             check(lib().lc_groupnorm_apply_os(x.data_ptr(), x_bs, C_.byref(keep[0]),
                                               C_.byref(keep[1]) if len(keep) > 1 else None, _p(gamma),
@@ -915,7 +926,7 @@ def _groupnorm_split(x, x_bs, G, eps, gamma, beta, scale, shift, act_silu, packe
     st = _stream()
     hs = _find_stats(x, G)
     if hs is not None:
-        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots) for h in hs]
+        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots, h.unit) for h in hs]
         with _Timed("groupnorm", 8.0 * B * C * H * W):
             check(lib().lc_groupnorm_apply_os_split(
                 x.data_ptr(), x_bs, C_.byref(keep[0]), C_.byref(keep[1]) if len(keep) > 1 else None,
@@ -947,7 +958,7 @@ class GnStats:
         from ._lib import GnStatsInput, OctStats
 
         self.shape = shape
-        segs = [OctStats(h.buf.data_ptr(), h.channels, h.slots) for h in (oct_handles or ())]
+        segs = [OctStats(h.buf.data_ptr(), h.channels, h.slots, h.unit) for h in (oct_handles or ())]
         self._keep = (part, gamma, beta, scale, shift, oct_handles, segs)
         self._struct = GnStatsInput(_p(part), G, nch, float(eps), _p(gamma), _p(beta),
                                     _p(scale), _p(shift), ss_bs,
@@ -979,7 +990,7 @@ def groupnorm_stats(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, 
     for n_, t_ in (("gamma", gamma), ("beta", beta)):
         if t_ is not None:
             _req(t_, n_)
-    hs = _find_stats(x, G) if G <= 128 else None
+    hs = _find_stats(x, G, pairs_ok=True) if G <= 128 else None
     if hs is not None:
         return GnStats((B, C, H, W), None, G, 0, eps, gamma, beta, scale, shift, ss_bs, hs)
     n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)

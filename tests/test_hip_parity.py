@@ -266,6 +266,42 @@ def test_conv_fused_groupnorm_from_producer_stats(dev, B, C, H, W, G, ks, cfg):
         assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 8, 128), (1, 64, 32, 1024), (3, 64, 6, 96)])
+@pytest.mark.parametrize("cfg", [0, 23, 25, 13])
+def test_conv_fused_groupnorm_from_pair_stats(dev, B, C, H, W, cfg):
+    """GroupNorm32 at 64 / 128 channels has 2 / 4 channels per group: the producers leave one entry
+    per channel PAIR (emit_stats=2) and the consumer conv folds those -- same result as the two-pass
+    route; single producer (2 per group), concat of two producers with different tiles (4 per group),
+    and the bookkeeping: the apply kernels do not take pair entries."""
+    from lidarcrafter_amd import ops as K
+
+    x = seeded_randn(B, 32, H, W, seed=291).to(dev)
+    w1 = (seeded_randn(C, 32, 3, 3, seed=292) / 17.0).to(dev)
+    w2 = (seeded_randn(C, 32, 3, 3, seed=293) / 11.0).to(dev)
+    bias1 = (seeded_randn(C, seed=294) * 2.0).to(dev)
+    res = seeded_randn(B, C, H, W, seed=299).to(dev)
+    cat = torch.empty(B, 2 * C, H, W, device=dev)
+    K.conv2d_ring(x, K.PackedConv(), w1, bias1, res=res, out=cat[:, :C], tile_cfg=23 if H % 4 == 0 else 25,
+                  emit_stats=2)
+    K.conv2d_ring(x, K.PackedConv(), w2, None, out=cat[:, C:], tile_cfg=13, emit_stats=2)
+    assert K._find_stats(cat, 32) is None and K._find_stats(cat, 32, pairs_ok=True) is not None
+    for src, Ci in ((cat[:, :C], C), (cat, 2 * C)):
+        wc = (seeded_randn(64, Ci, 3, 3, seed=295) / (Ci * 9) ** 0.5).to(dev)
+        ga, be = (1 + 0.1 * seeded_randn(Ci, seed=296)).to(dev), (0.1 * seeded_randn(Ci, seed=297)).to(dev)
+        ss = (0.3 * seeded_randn(B, 2 * Ci, seed=298)).to(dev)
+        st = K.groupnorm_stats(src, 32, 1e-6, ga, be, ss[:, :Ci], ss[:, Ci:])
+        assert st._struct.partials is None and st._struct.os0      # took the producers' pair entries
+        got = K.conv2d_ring(src, K.PackedConv(), wc, None, tile_cfg=cfg, gn_coeffs=st, gn_silu=True)
+        ref_in = src.clone()
+        st_ref = K.groupnorm_stats(ref_in, 32, 1e-6, ga, be, ss[:, :Ci], ss[:, Ci:])
+        assert st_ref._struct.partials is not None
+        ref = K.conv2d_ring(ref_in, K.PackedConv(), wc, None, tile_cfg=cfg, gn_coeffs=st_ref, gn_silu=True)
+        assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
+    # the apply kernels fall back to their own statistics pass for such a tensor (no error)
+    y = K.groupnorm(cat, 32, 1e-6, act_silu=True)
+    assert rel_l2(y, K.groupnorm(cat.clone(), 32, 1e-6, act_silu=True)) == 0.0
+
+
 def test_groupnorm_large_mean(dev):
     """fp64 partial sums: no catastrophic cancellation when |mean| >> std."""
     from lidarcrafter_amd import ops as K
