@@ -223,10 +223,12 @@ def train_step(dev, B):
     flop = 3 * B * GFLOP["uncond32"] * 1e9                       # forward + dX + dW
     return {"batch": B, "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2),
             "algorithmic_tflops": round(flop / dt / 1e12, 1),
-            "train_conv_precision": AGm.TRAIN_CONV_PRECISION,
+            "train_conv_precision": AGm.TRAIN_CONV_PRECISION, "train_wgrad_precision": AGm.TRAIN_WGRAD_PRECISION,
             "note": "forward + backward + AdamW; forward / dX convolutions in the precision named by "
                     "train_conv_precision (lidarcrafter_amd.autograd.TRAIN_CONV_PRECISION, env "
-                    "LC_TRAIN_CONV_PRECISION; default f16x2 split), weight gradient exact-fp32 MFMA"}
+                    "LC_TRAIN_CONV_PRECISION; default f16x2 split), weight gradient by train_wgrad_precision "
+                    "(LC_TRAIN_WGRAD_PRECISION; default f16x2 split, exact fp32 where the shape has no whole "
+                    "2 x 32 pixel tiles)"}
 
 
 def train_step_cond(dev, B):
@@ -236,6 +238,7 @@ def train_step_cond(dev, B):
     from lidargen.utils import inference
     from lidargen.utils.configs import __all__ as C
 
+    from lidarcrafter_amd import autograd as AGm
     ddpm, model, _ = inference.load_model_duffusion_training(C["nuscenes-box-layout-v6"]())
     seeded_fill(model, salt=200), seeded_fill(ddpm.condition_model, salt=201)
     ddpm = ddpm.train().to(dev)
@@ -253,7 +256,9 @@ def train_step_cond(dev, B):
     flop = 3 * B * GFLOP["cond32"] * 1e9
     return {"batch": B, "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 2),
             "algorithmic_tflops": round(flop / dt / 1e12, 1),
-            "note": "denoiser + layout encoder, forward + backward + AdamW, exact-fp32 MFMA convolutions, dropout as configured"}
+            "train_conv_precision": AGm.TRAIN_CONV_PRECISION, "train_wgrad_precision": AGm.TRAIN_WGRAD_PRECISION,
+            "note": "denoiser + layout encoder, forward + backward + AdamW, dropout as configured; convolutions "
+                    "as in train_step_c2; attention core / softmax / small dense layers are torch ops on the device"}
 
 
 def object_branch(dev, n_obj, steps):
