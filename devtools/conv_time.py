@@ -1,5 +1,6 @@
 """Time one conv shape (graph of 20 launches) with the library named by LC_HIP_LIB.
-    python devtools/conv_time.py B:Ci:Co:H:W[:ks] [--gn] [--res] [--emit] [--cfg N]"""
+    python devtools/conv_time.py B:Ci:Co:H:W[:ks] ... [--gn] [--res] [--emit] [--cfg N]
+    python devtools/conv_time.py B Ci Co H W ks cfg [--gn] [--res] [--emit]"""
 import os
 import sys
 import time
@@ -13,6 +14,9 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 0
 if "--cfg" in sys.argv:
     args = [a for a in args if a != str(cfg)]
+if len(args) >= 7 and ":" not in args[0]:        # older form (devtools/pmc_conv.sh): B Ci Co H W ks cfg
+    cfg = int(args[6])
+    args = [":".join(args[:6])]
 dev = torch.device("cuda:0")
 for shape in args:
     v = [int(t) for t in shape.split(":")]

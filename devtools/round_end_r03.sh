@@ -14,3 +14,6 @@ timeout 600 python bench.py 2>&1 | tail -1 > $O/bench.json
 find $O -name "*kernel_trace.csv" -delete
 timeout 600 python devtools/bench_rows.py > $O/rows.json 2> $O/rows.err
 cat $O/pytest.txt $O/smoke.txt 2>/dev/null; head -c 1500 $O/bench.json; echo; du -sh $O
+# PMC block of the level-0 launch (fused GroupNorm + residual + statistics, as in the C2 step)
+rm -rf gpurun_out/pmcc; timeout 600 bash devtools/pmc_conv.sh 8 64 64 32 1024 3 0 --gn --emit --res > $O/pmc_level0.txt 2>&1
+tail -25 $O/pmc_level0.txt
