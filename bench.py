@@ -109,6 +109,8 @@ def measure_hbm_traffic(timeout_s: int = 150):
     tool = shutil.which("rocprofv3")
     if tool is None:
         return None, "rocprofv3 not on PATH"
+    if any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR")):
+        return None, "this process already runs under a profiler tool: nested PMC passes skipped"
     totals = {}
     tmp = tempfile.mkdtemp(prefix="lc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
