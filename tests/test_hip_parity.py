@@ -302,6 +302,36 @@ def test_conv_fused_groupnorm_from_pair_stats(dev, B, C, H, W, cfg):
     assert rel_l2(y, K.groupnorm(cat.clone(), 32, 1e-6, act_silu=True)) == 0.0
 
 
+@pytest.mark.parametrize("unit", [8, 2])
+def test_epilogue_statistics_entries_under_load(dev, unit):
+    """Every entry the deferred epilogue writes, at the level-0 shape of the bench (8 x 64 x 32 x 1024, fused
+    input GroupNorm + residual, ~27 stores in flight per wave), against a recomputation from the stored
+    output -- repeated launches: a store-data hazard of back-to-back 128-bit stores once corrupted single
+    dwords of pair entries sporadically (profiles/r03_conv_phases.txt)."""
+    from lidarcrafter_amd import ops as K
+
+    B, C, H, W = 8, 64, 32, 1024
+    x = seeded_randn(B, C, H, W, seed=301).to(dev)
+    w = (seeded_randn(C, C, 3, 3, seed=302) / 17.0).to(dev)
+    res = seeded_randn(B, C, H, W, seed=303).to(dev)
+    gn = K.groupnorm_stats(x, 32 if unit == 2 else 8, 1e-6)
+    for rep in range(6):
+        y = K.conv2d_ring(x, K.PackedConv(), w, None, tile_cfg=23, emit_stats=True if unit == 8 else 2,
+                          gn_coeffs=gn, res=res)
+        h = y._lc_gnstats[(0, C)]
+        assert h.unit == unit and h.slots == (H // 4) * (W // 64) * 4
+        e = h.buf.double()                                             # [B, C / unit, slots, 4]
+        # slot = (tile_row * tiles_w + tile_col) * 4 + px_wave; a wave owns image row px_wave of the 4 x 64 tile
+        yv = y.double().view(B, C // unit, unit, H // 4, 4, W // 64, 64).permute(0, 1, 3, 5, 4, 2, 6)
+        ref = yv.reshape(B, C // unit, h.slots, unit * 64)
+        rs, rq = ref.sum(-1), (ref * ref).sum(-1)
+        p, n, s_, q = e[..., 0], e[..., 1], e[..., 2], e[..., 3]
+        assert torch.equal(n, torch.full_like(n, unit * 64.0))
+        es, eq = p * n + s_, q + 2 * p * s_ + p * p * n
+        assert float((es - rs).abs().max()) < 2e-3, (rep, float((es - rs).abs().max()))
+        assert float(((eq - rq).abs() / rq.clamp(min=1.0)).max()) < 1e-4, rep
+
+
 def test_groupnorm_large_mean(dev):
     """fp64 partial sums: no catastrophic cancellation when |mean| >> std."""
     from lidarcrafter_amd import ops as K
