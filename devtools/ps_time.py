@@ -1,0 +1,39 @@
+"""Time the pre-split 3x3 conv (GroupNorm-apply output as hi / lo planes -> LDS-DMA kernel) on the C2 layer shapes.
+    LC_HIP_LIB=<variant> python devtools/ps_time.py [B]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from lidarcrafter_amd import ops as K  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda:0")
+for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 128), (256, 128, 16, 512)):
+    x = torch.randn(B, Ci, H, W, device=dev)
+    w = torch.randn(Co, Ci, 3, 3, device=dev) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, device=dev)
+    res = torch.randn(B, Co, H, W, device=dev)
+    pk = K.PackedConv()
+    out = torch.empty(B, Co, H, W, device=dev)
+    sa = K.groupnorm(x, 8, 1e-6, act_silu=True, split_for=pk)
+    assert isinstance(sa, K.SplitAct)
+    f = lambda: K.conv2d_ring(sa, pk, w, b, out=out, res=res, out_scale=0.7071, emit_stats=True)
+    for _ in range(3):
+        f()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            f()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        g.replay()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 20)
+    fl = 2.0 * B * H * W * Ci * Co * 9
+    print(f"ps {B}:{Ci}:{Co}:{H}:{W}: {min(ts) * 1e6:.1f} us  {fl / min(ts) / 1e12:.0f} TF")

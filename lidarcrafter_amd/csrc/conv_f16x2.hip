@@ -55,7 +55,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
                       // 16 no residual loads, 32 no MFMAs
 #endif
 #ifndef LC_PS_ABL
-#define LC_PS_ABL 0   // pre-split kernel ablation: 1 no DMA in the K loop, 2 no MFMAs, 4 no x DMA, 8 no w DMA
+#define LC_PS_ABL 0   // pre-split kernel ablation: 1 no DMA in the K loop, 2 no MFMAs, 4 no x DMA, 8 no w DMA, 16 no epilogue stores / residual loads
 #endif
 #ifndef LC_EMIT_ABL
 #define LC_EMIT_ABL 0   // pre-split kernel, statistics epilogue ablation: 1 no per-element sums, 2 no reductions / stores
@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    res_r[i][j][r] = (rb && pok && co < a.Co) ? rb[(long long)co * HW + poff] : 0.0f;
+                    res_r[i][j][r] = (rb && pok && co < a.Co && !(LC_PS_ABL & 16)) ? rb[(long long)co * HW + poff] : 0.0f;
                 }
         }
     };
@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
                     const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
                                     a.out_scale;
-                    if (pok && co < a.Co) epi_store(&yb[(long long)co * HW + poff], v);
+                    if (pok && co < a.Co && !(LC_PS_ABL & 16)) epi_store(&yb[(long long)co * HW + poff], v);
                     if constexpr (EMIT_STATS && !(LC_EMIT_ABL & 1)) {
                         const int m = r >> 2;
                         if (j == 0 && (r & 3) == 0) {
