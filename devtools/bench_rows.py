@@ -52,6 +52,47 @@ def uncond(dev, B, res, steps, key):
             "frac_of_f16_mfma_peak": round(B * GFLOP[key] / dt / 1e3 / 2500.0, 4)}
 
 
+def uncond_autocast(dev, B, steps):
+    """The reference's bulk harness runs the sampler under torch.autocast(float16)
+    (tools/evaluation/sample_and_save_cond.py:64,145): with LC_AUTOCAST_SINGLE_PRODUCT the convolutions then
+    take ONE fp16 product per multiply (liblidarcrafter_hip_p1.so) -- fp16-autocast-class accuracy, NOT the
+    fp32-class arithmetic of the benchmarked path.  Reported with the deviation of its frames from the
+    three-product run on the same x_T."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model, _ = inference.load_model_duffusion_training(C["nuscenes-unet-uncond"]())
+    seeded_fill(model, salt=100)
+    ddpm = ddpm.eval().to(dev)
+    g = [torch.Generator().manual_seed(i) for i in range(B)]
+    x_T = torch.stack([torch.randn(*ddpm.sampling_shape, generator=r) for r in g]).to(dev)
+    def run10():
+        st_ = ddpm.begin_sampling(B, 10, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T.clone())
+        for _ in range(10):
+            x_ = ddpm.sampling_step(st_)
+        return x_.clone()
+
+    ref = run10()
+    old = K.AUTOCAST_SINGLE_PRODUCT
+    K.AUTOCAST_SINGLE_PRODUCT = True
+    try:
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert K.conv_products() == 1
+            st = ddpm.begin_sampling(B, steps + 3, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
+            dt = timed(lambda: ddpm.sampling_step(st), steps, warm=3)
+            assert torch.isfinite(st["x"]).all()
+            got = run10()
+            dev_frames = float(((got - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max())
+    finally:
+        K.AUTOCAST_SINGLE_PRODUCT = old
+    return {"batch": B, "resolution": [32, 1024], "ms_per_step": round(dt * 1e3, 3), "steps_per_s": round(1 / dt, 2),
+            "conv_products": 1, "frames_rel_l2_vs_three_products_10_ddim_steps": dev_frames,
+            "note": "fp16-autocast caller, single fp16 product per multiply; a precision-reduced row, not the "
+                    "headline arithmetic"}
+
+
 def cond(dev, B, steps):
     from lidarcrafter_amd.testing import seeded_fill, synth_layout_batch
     from lidargen.utils import inference
@@ -312,6 +353,7 @@ def main():
                                    for B in ((1, 8) if q else (1, 2, 8, 32))],
         "cond_layout_v6_32x1024": lambda: [cond(dev, B, 10) for B in ((8,) if q else (1, 8))],
         "uncond_64x2048": lambda: [] if q else [uncond(dev, 4, (64, 2048), 6, "uncond64")],
+        "uncond_32x1024_fp16_autocast_single_product": lambda: [uncond_autocast(dev, 8, 20)],
         "temporal_sequence_32x1024": lambda: [sequence(dev, 2, 5, 16 if q else 32)],
         "pipeline_metrics_c5_shape": lambda: [pipeline_metrics(dev, 8, 1 if q else 2, 8)],
         "train_step_c2": lambda: [train_step(dev, B) for B in ((2,) if q else (2, 8))],

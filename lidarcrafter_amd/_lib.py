@@ -141,6 +141,25 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_lib_p1 = None
+
+
+def lib_p1() -> C.CDLL:
+    """The single-product build of the convolution kernels (liblidarcrafter_hip_p1.so, -DLC_F16X2_TERMS=1):
+    same entry points and arguments as the product library, used only through ops.conv_products() == 1."""
+    global _lib_p1
+    if _lib_p1 is None:
+        path = os.path.join(os.path.dirname(LIB), "liblidarcrafter_hip_p1.so")
+        if not os.path.exists(path):
+            raise HipLibraryMissing(f"{path} not found: run `python -m lidarcrafter_amd.build`")
+        handle = C.CDLL(path)
+        for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd"):
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = SIGNATURES[name]
+        _lib_p1 = handle
+    return _lib_p1
+
+
 class HipError(RuntimeError):
     pass
 

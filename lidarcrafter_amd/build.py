@@ -9,6 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblidarcrafter_hip.so")
+# the convolution kernels alone with ONE fp16 product per multiply (-DLC_F16X2_TERMS=1): what a caller under
+# torch.autocast(float16) asked for (the reference's bulk harness); never used otherwise (ops.conv_products)
+LIB_P1 = os.path.join(HERE, "liblidarcrafter_hip_p1.so")
 SOURCES = ["conv.hip", "conv_f16x2.hip", "norm.hip", "resample.hip", "misc.hip", "attention.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip", "conv_bwd.hip"]
 
 
@@ -22,7 +25,9 @@ def hipcc() -> str:
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
+    if not os.path.exists(LIB_P1):
+        return True
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_P1))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "lidarcrafter_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
@@ -40,6 +45,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
                os.path.join(CSRC, src), "-o", obj] + os.environ.get("LC_EXTRA_HIPCC_FLAGS", "").split()
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
+    p1_obj = os.path.join(HERE, "build", "conv_f16x2_p1.o")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DLC_F16X2_TERMS=1", "-c",
+           os.path.join(CSRC, "conv_f16x2.hip"), "-o", p1_obj] + os.environ.get("LC_EXTRA_HIPCC_FLAGS", "").split()
+    procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -48,8 +57,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(out.decode())
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_P1, p1_obj], check=True)
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "and", os.path.basename(LIB_P1))
     return LIB
 
 

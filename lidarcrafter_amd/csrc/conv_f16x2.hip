@@ -74,8 +74,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #endif
 #ifndef LC_F16X2_TERMS
 // which of the three products are accumulated: bit 0 wh*xh, bit 1 wl*xh, bit 2 wh*xl.  7 in the
-// product; 1 / 3 / 5 exist only to MEASURE what fewer passes cost in accuracy
-// (devtools/passes_error.py, profiles/r02_passes_error.json).
+// product library; 3 / 5 exist only to MEASURE what fewer passes cost in accuracy
+// (devtools/passes_error.py, profiles/r02_passes_error.json); 1 = the single-product build
+// liblidarcrafter_hip_p1.so that serves callers running under fp16 autocast (ops.conv_products).
 #define LC_F16X2_TERMS 7
 #endif
 #if LC_TIMING
@@ -1433,16 +1434,20 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
             for (int q = 0; q < SPT; ++q)
                 if (tap * SPT + q < IPW) issue_slot(nxt, tap * SPT + q, xso, wso);
             if (LC_PS_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+            if (LC_F16X2_TERMS & 2) {
 #pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
+                for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::TPX_; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+            }
+            if (LC_F16X2_TERMS & 4) {
 #pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
+                for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll
-                for (int j = 0; j < C::TPX_; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::TPX_; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < C::TCO_; ++i)
 #pragma unroll

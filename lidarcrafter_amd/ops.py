@@ -141,6 +141,40 @@ def fuse_gn(out_channels: int = 0) -> bool:
 FUSE_GN_MAX_CO = int(_os.environ.get("LC_FUSE_GN_MAX_CO", "64"))
 
 
+# Products per multiply of the f16x2 convolutions: 3 = the split (fp32-class accuracy, the product path and
+# every parity claim); 1 = ONE fp16 product with fp32 accumulation (operands rounded to 11 bits) -- what
+# fp16 autocast computes in the reference.  Opt-in only: set_conv_products(1), or LC_AUTOCAST_SINGLE_PRODUCT=1
+# to take it while (and only while) the caller runs under torch.autocast(dtype=float16), as the reference's
+# bulk harness does (tools/evaluation/sample_and_save_cond.py:64,145).  Frames of a 50-step run differ from the
+# fp32 reference by ~1.4e-2 in this mode (profiles/r02_passes_error.json): it is NOT the benchmarked path.
+_CONV_PRODUCTS = 1 if _os.environ.get("LC_CONV_PRODUCTS") == "1" else 3
+AUTOCAST_SINGLE_PRODUCT = _os.environ.get("LC_AUTOCAST_SINGLE_PRODUCT", "0") == "1"
+
+
+def set_conv_products(n: int) -> int:
+    global _CONV_PRODUCTS
+    if n not in (1, 3):
+        raise ValueError("conv products: 1 or 3")
+    old, _CONV_PRODUCTS = _CONV_PRODUCTS, n
+    return old
+
+
+def conv_products() -> int:
+    if _CONV_PRODUCTS == 1:
+        return 1
+    if AUTOCAST_SINGLE_PRODUCT and torch.is_autocast_enabled() and \
+            torch.get_autocast_gpu_dtype() == torch.float16:
+        return 1
+    return 3
+
+
+def _conv_lib():
+    if conv_products() == 1:
+        from ._lib import lib_p1
+        return lib_p1()
+    return lib()
+
+
 def set_conv_precision(mode: str) -> str:
     global CONV_PRECISION
     if mode not in ("f32", "f16x2"):
@@ -741,7 +775,7 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, Ci, Co, H, W, ks, int(tile_cfg)))
                 if slots > 0:
                     sbuf = torch.empty((B, Co // unit, slots, 4), device=x.device, dtype=_F32)
-            check(lib().lc_conv2d_ring_f16x2_fwd(x.data_ptr(), x_bs, wh.data_ptr(), wl.data_ptr(),
+            check(_conv_lib().lc_conv2d_ring_f16x2_fwd(x.data_ptr(), x_bs, wh.data_ptr(), wl.data_ptr(),
                                                  _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                  Ci, Co, H, W, ks, float(out_scale),
                                                  int(tile_cfg), _p(gn_coeffs), cpad, int(gn_silu),
@@ -792,7 +826,7 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
         if ks >= 2:
             # small grid: ksplit blocks per tile over disjoint K ranges + one deterministic reduce
             part = torch.empty((ks, B, Co, H, W), device=dev, dtype=_F32)
-            check(lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+            check(_conv_lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
                                                     None, None, 0, None, 0, B, Ci, Co, H, W, 1.0, 0,
                                                     None, part.data_ptr(), ks,
                                                     packed.wmeta.data_ptr(), packed.range_ptr(dev),
@@ -809,7 +843,7 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                                                                    int(tile_cfg)))
                 if slots > 0:
                     sbuf = torch.empty((B, Co // 8, slots, 4), device=dev, dtype=_F32)
-            check(lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+            check(_conv_lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
                                                     _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                     Ci, Co, H, W, float(out_scale), int(tile_cfg),
                                                     _p(sbuf), None, 0, packed.wmeta.data_ptr(),

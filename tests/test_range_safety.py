@@ -229,3 +229,40 @@ def test_training_forward_does_not_poll(dev, monkeypatch):
     with torch.no_grad():
         m.eval()(x, torch.tensor([-2.0, 1.0], device=dev))
     assert len(calls) == 1
+
+
+def test_single_product_mode_is_opt_in_and_close(dev):
+    """ops.conv_products(): 3 unless asked otherwise; 1 (liblidarcrafter_hip_p1.so: one fp16 product per
+    multiply) only through set_conv_products(1) or, with AUTOCAST_SINGLE_PRODUCT, inside fp16 autocast.  Both conv
+    kernels (fp32 input, pre-split input) then differ from the three-product result by the 11-bit operand
+    rounding -- about 1e-3 -- and by nothing more."""
+    from lidarcrafter_amd import ops as K
+
+    assert K.conv_products() == 3
+    x = seeded_randn(2, 64, 8, 256, seed=401).to(dev)
+    w = (seeded_randn(64, 64, 3, 3, seed=402) / 24.0).to(dev)
+    b = seeded_randn(64, seed=403).to(dev)
+    pk = K.PackedConv()
+    y3 = K.conv2d_ring(x, pk, w, b)
+    sa = K.groupnorm(x, 8, 1e-6, act_silu=True, split_for=pk)
+    z3 = K.conv2d_ring(sa, pk, w, b)
+    old = K.set_conv_products(1)
+    try:
+        assert K.conv_products() == 1
+        y1 = K.conv2d_ring(x, pk, w, b)
+        z1 = K.conv2d_ring(K.groupnorm(x, 8, 1e-6, act_silu=True, split_for=pk), pk, w, b)
+    finally:
+        K.set_conv_products(old)
+    for a1, a3 in ((y1, y3), (z1, z3)):
+        r = rel_l2(a1, a3)
+        assert 1e-5 < r < 3e-3, r                      # rounded operands: different, and only that different
+    assert torch.equal(K.conv2d_ring(x, pk, w, b), y3)          # back on the product path, bit for bit
+    K.AUTOCAST_SINGLE_PRODUCT = True
+    try:
+        assert K.conv_products() == 3
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert K.conv_products() == 1
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert K.conv_products() == 3
+    finally:
+        K.AUTOCAST_SINGLE_PRODUCT = False
