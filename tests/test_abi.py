@@ -184,3 +184,14 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3   # steps/s of the job
+
+
+def test_single_product_library_loads():
+    """liblidarcrafter_hip_p1.so (the convolution kernels with one fp16 product per multiply, for fp16-autocast
+    callers) is built next to the product library and exports the two entry points ops routes to it."""
+    from lidarcrafter_amd import _lib, ops
+
+    h = _lib.lib_p1()
+    for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd"):
+        assert getattr(h, name).argtypes == _lib.SIGNATURES[name][1]
+    assert ops.conv_products() == 3            # never the default
