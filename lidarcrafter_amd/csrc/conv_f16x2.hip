@@ -72,6 +72,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_PS_SCHED
 #define LC_PS_SCHED 0   // pre-split kernel: 0 = fence per tap (reads of tap t+1, then MFMAs of tap t), 1 = 1:1 interleave
 #endif
+#ifndef LC_ENTRY_DWORD_STORES
+// 1: the deferred epilogue writes a statistics entry as four 32-bit stores with four different cache-policy bits
+// (the load/store optimizer then cannot merge them back into one dwordx4) instead of one 128-bit store -- the
+// candidate fix for the entry corruption under load (see DefEpi).  NOT YET VALIDATED ON HARDWARE (the round's GPU
+// budget ended; the first attempt failed because __builtin_bit_cast(unsigned, vec.y) on an ext-vector element is
+// compiled as a read of element 0 -- __float_as_uint(vec.y) is right).  Default 0 = the tested 128-bit form.
+#define LC_ENTRY_DWORD_STORES 0
+#endif
 #ifndef LC_F16X2_TERMS
 // which of the three products are accumulated: bit 0 wh*xh, bit 1 wl*xh, bit 2 wh*xl.  7 in the
 // product library; 3 / 5 exist only to MEASURE what fewer passes cost in accuracy
@@ -708,7 +716,18 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
                 typedef __attribute__((ext_vector_type(4))) unsigned u4;
                 const int oct = i * 4 + m;               // octet index inside this wave's channel rows
                 const bool ok = ent_off != OOB && co_wave + i * 32 + 8 * m < Co;   // (co_wave carries 4 * kh <= 4)
-                if constexpr (!pairs) {                  // one entry from lane 63
+                if constexpr (LC_ENTRY_DWORD_STORES != 0) {
+                    const unsigned vo = ok ? ent_off : OOB;
+                    if constexpr (!pairs) {
+                        store_entry32(st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q), vo,
+                                      (unsigned)oct * oct_stride);
+                    } else {
+                        store_entry32(st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q), vo,
+                                      (unsigned)(4 * oct) * oct_stride);
+                        store_entry32(st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2), vo,
+                                      (unsigned)(4 * oct + 1) * oct_stride);
+                    }
+                } else if constexpr (!pairs) {           // one entry from lane 63
                     const f32x4 e = {st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q)};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e), rs_o, ok ? ent_off : OOB,
                                                            (unsigned)oct * oct_stride, 0);
@@ -735,8 +754,16 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             // ds_read_b128 two instructions later) and stored entries sporadically carried foreign data in
             // one dword -- 8-wave tiles only, where the store waits in a saturated memory pipeline
             // (profiles/r03_conv_phases.txt, "pair entries").
-            if constexpr (pairs) asm volatile("" : "+v"(ent0), "+v"(ent1));
+            if constexpr (pairs && LC_ENTRY_DWORD_STORES == 0) asm volatile("" : "+v"(ent0), "+v"(ent1));
         }
+    }
+    // LC_ENTRY_DWORD_STORES: (pivot, n, s, q) as four 32-bit stores that cannot be merged (distinct cache policies)
+    __device__ __forceinline__ void store_entry32(float p_, float n_, float s_, float q_, unsigned voffset,
+                                                  unsigned soffset) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p_), rs_o, voffset, soffset, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(n_), rs_o, voffset, soffset + 4u, 1);     // sc0
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_), rs_o, voffset, soffset + 8u, 16);    // sc1
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q_), rs_o, voffset, soffset + 12u, 17);   // sc0 sc1
     }
     // slot s of the deferred stream (s static after unrolling)
     __device__ __forceinline__ void slot(int s) {
@@ -755,7 +782,7 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             n += ((s + LAG) * VPT + u < NV) ? 1 : 0;
             const int k = s * VPT + u;
             n += (k < NV) ? 1 : 0;
-            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) : 0;
+            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) * (LC_ENTRY_DWORD_STORES ? 4 : 1) : 0;
         }
         return n;
     }
