@@ -33,7 +33,8 @@ def _producer_stats_where_tested(request, monkeypatch):
     """Producer-side GroupNorm statistics are off by default (ops.PRODUCER_GN_STATS: open store hazard,
     profiles/r03_conv_phases.txt); the tests that exercise them switch them on for themselves."""
     name = request.node.name
-    if any(k in name for k in ("stats", "under_load", "producer", "split_k", "concat_segments", "groupnorm_split_matches")):
+    if any(k in name for k in ("stats", "under_load", "producer", "split_k", "concat_segments", "groupnorm_split_matches",
+                                "presplit_vs_oracle")):
         from lidarcrafter_amd import ops as K
         monkeypatch.setattr(K, "PRODUCER_GN_STATS", True)
     yield
