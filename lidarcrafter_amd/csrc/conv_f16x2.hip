@@ -77,7 +77,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // (the load/store optimizer then cannot merge them back into one dwordx4) instead of one 128-bit store -- the
 // candidate fix for the entry corruption under load (see DefEpi).  NOT YET VALIDATED ON HARDWARE (the round's GPU
 // budget ended; the first attempt failed because __builtin_bit_cast(unsigned, vec.y) on an ext-vector element is
-// compiled as a read of element 0 -- __float_as_uint(vec.y) is right).  Default 0 = the tested 128-bit form.
+// compiled as a read of element 0 -- __float_as_uint(vec.y) is right).  2: a 128-bit store without SGPR soffset (the
+// compiler then inserts the ISA's wait state for wide store data itself).  Default 0 = the tested 128-bit form.
 #define LC_ENTRY_DWORD_STORES 0
 #endif
 #ifndef LC_F16X2_TERMS
@@ -716,7 +717,23 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
                 typedef __attribute__((ext_vector_type(4))) unsigned u4;
                 const int oct = i * 4 + m;               // octet index inside this wave's channel rows
                 const bool ok = ent_off != OOB && co_wave + i * 32 + 8 * m < Co;   // (co_wave carries 4 * kh <= 4)
-                if constexpr (LC_ENTRY_DWORD_STORES != 0) {
+                if constexpr (LC_ENTRY_DWORD_STORES == 2) {
+                    // second candidate: keep the 128-bit store but fold the unit offset into the VGPR offset
+                    // (soffset = 0): LLVM's ">64-bit store data" wait state applies to MUBUF stores WITHOUT an SGPR
+                    // soffset, so hipcc then guards the data registers itself
+                    if constexpr (!pairs) {
+                        const f32x4 e = {st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q)};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e), rs_o,
+                                                               ok ? ent_off + (unsigned)oct * oct_stride : OOB, 0u, 0);
+                    } else {
+                        const f32x4 e0 = {st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q)};
+                        const f32x4 e1 = {st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2)};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e0), rs_o,
+                                                               ok ? ent_off + (unsigned)(4 * oct) * oct_stride : OOB, 0u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e1), rs_o,
+                                                               ok ? ent_off + (unsigned)(4 * oct + 1) * oct_stride : OOB, 0u, 0);
+                    }
+                } else if constexpr (LC_ENTRY_DWORD_STORES != 0) {
                     const unsigned vo = ok ? ent_off : OOB;
                     if constexpr (!pairs) {
                         store_entry32(st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q), vo,
@@ -754,7 +771,7 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             // ds_read_b128 two instructions later) and stored entries sporadically carried foreign data in
             // one dword -- 8-wave tiles only, where the store waits in a saturated memory pipeline
             // (profiles/r03_conv_phases.txt, "pair entries").
-            if constexpr (pairs && LC_ENTRY_DWORD_STORES == 0) asm volatile("" : "+v"(ent0), "+v"(ent1));
+            if constexpr (pairs && LC_ENTRY_DWORD_STORES == 0) asm volatile("" : "+v"(ent0), "+v"(ent1));   // (0 only)
         }
     }
     // LC_ENTRY_DWORD_STORES: (pivot, n, s, q) as four 32-bit stores that cannot be merged (distinct cache policies)
@@ -782,7 +799,7 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             n += ((s + LAG) * VPT + u < NV) ? 1 : 0;
             const int k = s * VPT + u;
             n += (k < NV) ? 1 : 0;
-            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) * (LC_ENTRY_DWORD_STORES ? 4 : 1) : 0;
+            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) * (LC_ENTRY_DWORD_STORES == 1 ? 4 : 1) : 0;
         }
         return n;
     }
