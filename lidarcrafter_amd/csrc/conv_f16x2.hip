@@ -25,6 +25,7 @@
 //             (coalesced along W), splits, and writes [cb][row][col] 16-byte units into LDS.
 // Reference semantics: ops.Conv2d + ops.Pad, lidargen/models/unets/ops.py:32-49,149-173.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -71,15 +72,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #endif
 #ifndef LC_PS_SCHED
 #define LC_PS_SCHED 0   // pre-split kernel: 0 = fence per tap (reads of tap t+1, then MFMAs of tap t), 1 = 1:1 interleave
-#endif
-#ifndef LC_ENTRY_DWORD_STORES
-// 1: the deferred epilogue writes a statistics entry as four 32-bit stores with four different cache-policy bits
-// (the load/store optimizer then cannot merge them back into one dwordx4) instead of one 128-bit store -- the
-// candidate fix for the entry corruption under load (see DefEpi).  NOT YET VALIDATED ON HARDWARE (the round's GPU
-// budget ended; the first attempt failed because __builtin_bit_cast(unsigned, vec.y) on an ext-vector element is
-// compiled as a read of element 0 -- __float_as_uint(vec.y) is right).  2: a 128-bit store without SGPR soffset (the
-// compiler then inserts the ISA's wait state for wide store data itself).  Default 0 = the tested 128-bit form.
-#define LC_ENTRY_DWORD_STORES 0
 #endif
 #ifndef LC_F16X2_TERMS
 // which of the three products are accumulated: bit 0 wh*xh, bit 1 wl*xh, bit 2 wh*xl.  7 in the
@@ -600,7 +592,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
         LC_WV(0) LC_WV(1) LC_WV(2) LC_WV(3) LC_WV(4) LC_WV(5) LC_WV(6) LC_WV(7) LC_WV(8) LC_WV(9) LC_WV(10)
         LC_WV(11) LC_WV(12) LC_WV(13) LC_WV(14) LC_WV(15) LC_WV(16) LC_WV(17) LC_WV(18) LC_WV(19) LC_WV(20)
         LC_WV(21) LC_WV(22) LC_WV(23) LC_WV(24) LC_WV(25) LC_WV(26) LC_WV(27) LC_WV(28) LC_WV(29) LC_WV(30)
-        LC_WV(31) LC_WV(32)
+        LC_WV(31) LC_WV(32) LC_WV(33) LC_WV(34) LC_WV(35) LC_WV(36) LC_WV(37) LC_WV(38) LC_WV(39) LC_WV(40)
+        LC_WV(41) LC_WV(42) LC_WV(43) LC_WV(44) LC_WV(45) LC_WV(46) LC_WV(47) LC_WV(48) LC_WV(49) LC_WV(50)
+        LC_WV(51) LC_WV(52) LC_WV(53) LC_WV(54) LC_WV(55) LC_WV(56) LC_WV(57) LC_WV(58) LC_WV(59) LC_WV(60)
+        LC_WV(61) LC_WV(62) LC_WV(63)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef LC_WV
@@ -648,7 +643,6 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
     float rq[RING];
     float st_p, st_s, st_q;    // the running octet: pivot, sum (v - p), sum (v - p)^2 of channels q = 0, 1 of each quad
     float st_s2, st_q2;        // pair entries: ... and of channels q = 2, 3 (unused for octet entries)
-    f32x4 ent0, ent1;          // pair entries: the two entries of the last octet (see finalize_with)
     static constexpr bool pairs = EMIT == 2;   // entries per channel pair (ConvArgsH::ounit == 2)
     unsigned voff[TPX];        // byte offset of (channel co_wave, pixel j) in the sample; OOB = nothing to do
     __amdgpu_buffer_rsrc_t rs_y, rs_r, rs_o;
@@ -673,7 +667,6 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
         oct_stride = (unsigned)oslots * 16u;
         nv8 = 0.f; ent_off = OOB;
         st_p = st_s = st_q = st_s2 = st_q2 = 0.f;
-        ent0 = ent1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TPX; ++j) voff[j] = OOB;
 #pragma unroll
@@ -714,73 +707,42 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             if (pairs && (k & 2)) { st_s2 += d; st_q2 = fmaf(d, d, st_q2); }   // (k & 3 = channel inside the lane's quad)
             else { st_s += d; st_q = fmaf(d, d, st_q); }
             if (k % OCTV == OCTV - 1) {                  // the octet is complete
-                typedef __attribute__((ext_vector_type(4))) unsigned u4;
                 const int oct = i * 4 + m;               // octet index inside this wave's channel rows
                 const bool ok = ent_off != OOB && co_wave + i * 32 + 8 * m < Co;   // (co_wave carries 4 * kh <= 4)
-                if constexpr (LC_ENTRY_DWORD_STORES == 2) {
-                    // second candidate: keep the 128-bit store but fold the unit offset into the VGPR offset
-                    // (soffset = 0): LLVM's ">64-bit store data" wait state applies to MUBUF stores WITHOUT an SGPR
-                    // soffset, so hipcc then guards the data registers itself
-                    if constexpr (!pairs) {
-                        const f32x4 e = {st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q)};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e), rs_o,
-                                                               ok ? ent_off + (unsigned)oct * oct_stride : OOB, 0u, 0);
-                    } else {
-                        const f32x4 e0 = {st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q)};
-                        const f32x4 e1 = {st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2)};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e0), rs_o,
-                                                               ok ? ent_off + (unsigned)(4 * oct) * oct_stride : OOB, 0u, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e1), rs_o,
-                                                               ok ? ent_off + (unsigned)(4 * oct + 1) * oct_stride : OOB, 0u, 0);
-                    }
-                } else if constexpr (LC_ENTRY_DWORD_STORES != 0) {
-                    const unsigned vo = ok ? ent_off : OOB;
-                    if constexpr (!pairs) {
-                        store_entry32(st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q), vo,
-                                      (unsigned)oct * oct_stride);
-                    } else {
-                        store_entry32(st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q), vo,
-                                      (unsigned)(4 * oct) * oct_stride);
-                        store_entry32(st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2), vo,
-                                      (unsigned)(4 * oct + 1) * oct_stride);
-                    }
-                } else if constexpr (!pairs) {           // one entry from lane 63
-                    const f32x4 e = {st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q)};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, e), rs_o, ok ? ent_off : OOB,
-                                                           (unsigned)oct * oct_stride, 0);
+                // The entry goes out as ONE 32-bit store in which the four lanes below the reducing lane carry one
+                // field each (store_entry_lanes).  Rounds 1-3 wrote it as one 128-bit buffer store with an SGPR
+                // soffset; ~3 entries in 10^7 then arrived with a foreign upper dword (a VALU write of the data
+                // registers one or two instructions behind the store: LLVM exempts MUBUF stores with an SGPR soffset
+                // from the ISA's ">64-bit store data" wait state, and under ~27 stores in flight per wave that
+                // exemption does not hold on gfx950).  Measured in round 4 (devtools/entry_stress.py,
+                // profiles/r04_entry_store.txt): 128-bit + SGPR soffset 17 bad entries in 5e7, 32-bit stores 0 in
+                // 1e8.  32-bit stores fetch their data at issue -- the form every output value of this epilogue
+                // has always used.
+                const unsigned vo = ok ? ent_off : OOB;
+                if constexpr (!pairs) {                  // one entry from lane 63
+                    store_entry_lanes(st_p, nv8, wave_sum_to_lane63(st_s), wave_sum_to_lane63(st_q), vo,
+                                  (unsigned)oct * oct_stride);
                 } else {                                 // pairs (8m + 4kh + 0,1) and (+ 2,3) from lanes 31 / 63
-                    ent0 = f32x4{st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q)};
-                    ent1 = f32x4{st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2)};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ent0), rs_o, ok ? ent_off : OOB,
-                                                           (unsigned)(4 * oct) * oct_stride, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, ent1), rs_o, ok ? ent_off : OOB,
-                                                           (unsigned)(4 * oct + 1) * oct_stride, 0);
+                    store_entry_lanes(st_p, nv8, half_sum_to_lane31_63(st_s), half_sum_to_lane31_63(st_q), vo,
+                                  (unsigned)(4 * oct) * oct_stride);
+                    store_entry_lanes(st_p, nv8, half_sum_to_lane31_63(st_s2), half_sum_to_lane31_63(st_q2), vo,
+                                  (unsigned)(4 * oct + 1) * oct_stride);
                 }
             }
-            // OPEN HAZARD (round 3, profiles/r03_conv_phases.txt "statistics entries under load"): with ~27
-            // stores in flight per wave, about one statistics entry in 10^6 ... 10^7 is stored with one foreign
-            // dword -- octet entries too, not only the pair entries this work-around was written for; dedicating
-            // the entry registers cured the pair form in every run but not the octet form, and four 32-bit
-            // stores per entry broke the layer outright (cause not found within the round's GPU budget).  Effect
-            // on a run: one (sample, group) mean / variance off by ~1e-3 of the value scale now and then; the
-            // bench verifies its 50-step frames at ~1e-5 of the reference on every run.  LC_GN_PRODUCER_STATS=0
-            // selects the statistics-pass route, which has no such store.
-            // Pair entries only: the two entries live in registers of their own for the whole tile loop
-            // (the "+v" below makes them live and 'modified' at every value).  Without it hipcc reused an
-            // entry's data registers right behind its buffer_store_dwordx4 (e.g. as the destination of a
-            // ds_read_b128 two instructions later) and stored entries sporadically carried foreign data in
-            // one dword -- 8-wave tiles only, where the store waits in a saturated memory pipeline
-            // (profiles/r03_conv_phases.txt, "pair entries").
-            if constexpr (pairs && LC_ENTRY_DWORD_STORES == 0) asm volatile("" : "+v"(ent0), "+v"(ent1));   // (0 only)
         }
     }
-    // LC_ENTRY_DWORD_STORES: (pivot, n, s, q) as four 32-bit stores that cannot be merged (distinct cache policies)
-    __device__ __forceinline__ void store_entry32(float p_, float n_, float s_, float q_, unsigned voffset,
-                                                  unsigned soffset) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(p_), rs_o, voffset, soffset, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(n_), rs_o, voffset, soffset + 4u, 1);     // sc0
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_), rs_o, voffset, soffset + 8u, 16);    // sc1
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q_), rs_o, voffset, soffset + 12u, 17);   // sc0 sc1
+    // (pivot, n, s, q): the sums arrive in the reducing lane R (63, or 31 / 63 for pair entries), pivot and count are
+    // wave-uniform; lanes R-3 .. R store the fields 0 .. 3 (ent_off of those lanes = entry + 4 * field, OOB elsewhere):
+    // one store instruction per entry, no wide store data.  (First form of round 4: four 32-bit stores from lane R with
+    // four different cache-policy bits to keep the load/store optimizer from re-merging them -- the sc0 sc1 one cost
+    // the level-0 launch ~100 us.)
+    __device__ __forceinline__ void store_entry_lanes(float p_, float n_, float s_, float q_, unsigned voffset,
+                                                      unsigned soffset) {
+        // row_shl:1 -- lane R-1 reads lane R's sum
+        const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_), 0x101, 0xF, 0xF, true));
+        const unsigned f = threadIdx.x & 3;
+        const float v = f == 0 ? p_ : (f == 1 ? n_ : (f == 2 ? s1 : q_));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_o, voffset, soffset, 0);
     }
     // slot s of the deferred stream (s static after unrolling)
     __device__ __forceinline__ void slot(int s) {
@@ -799,7 +761,7 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             n += ((s + LAG) * VPT + u < NV) ? 1 : 0;
             const int k = s * VPT + u;
             n += (k < NV) ? 1 : 0;
-            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) * (LC_ENTRY_DWORD_STORES == 1 ? 4 : 1) : 0;
+            n += (EMIT && k < NV && k % OCTV == OCTV - 1) ? (EMIT == 2 ? 2 : 1) : 0;
         }
         return n;
     }
@@ -842,10 +804,10 @@ struct DefEpi {                // branch here split the MFMAs' basic block -- le
             const int slot_id = ((h0 / C::TH_) * tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
             if constexpr (!pairs) {
                 nv8 = (float)(8 * nvalid);
-                ent_off = lane == 63 ? (unsigned)(co_blk >> 3) * oct_stride + (unsigned)slot_id * 16u : OOB;
+                ent_off = lane >= 60 ? (unsigned)(co_blk >> 3) * oct_stride + (unsigned)slot_id * 16u + (unsigned)(lane & 3) * 4u : OOB;
             } else {
                 nv8 = (float)(2 * nvalid);
-                ent_off = l31 == 31 ? (unsigned)((co_blk >> 1) + 2 * (lane >> 5)) * oct_stride + (unsigned)slot_id * 16u : OOB;
+                ent_off = l31 >= 28 ? (unsigned)((co_blk >> 1) + 2 * (lane >> 5)) * oct_stride + (unsigned)slot_id * 16u + (unsigned)(lane & 3) * 4u : OOB;
             }
         }
         if (prefetch) {                                 // (the last tile is drained with its own loads)
@@ -1309,6 +1271,8 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
 }
 
 
+#include "conv_f16x2_pp.h"
+
 // ---------------------------------------------------------------------------------------------
 // PRE-SPLIT INPUT variant: the activation arrives as two fp16 planes (hi, lo) in channel-octet
 // innermost layout  xsp[b][plane][c/8][h][w][8]  -- written by the PRODUCER (the GroupNorm apply
@@ -1721,6 +1685,44 @@ int launch_h(ConvArgsH a, hipStream_t st) {
     return lc_launch_status();
 }
 
+// Ping-pong kernel (conv_f16x2_pp.h): shapes it takes, strips per block, launch.
+bool pp_eligible(int Ci, int Co, int H, int W, int ks) {
+    return ks == 3 && Ci % 32 == 0 && Ci >= 64 && Ci <= PPG::MAX_C && Co % 64 == 0 && H % 4 == 0 && W % 64 == 0;
+}
+int launch_pp(ConvArgsH a, hipStream_t st) {
+    if (!pp_eligible(a.Ci, a.Co, a.H, a.W, 3) || a.xsp || a.part) return LC_EUNSUP;
+    if (a.gn && a.Cgn > PPG::MAX_C) return LC_EUNSUP;
+    a.tiles_h = a.H / PPG::TH;
+    a.tiles_w = a.W / PPG::TW;
+    const int ncot = a.Co / PPG::BN;
+    // strips per block (walking down H): as many as leave one block per CU -- the epilogue of every strip but a
+    // block's last is hidden under the next strip
+    const long long strips = (long long)a.B * a.tiles_h * a.tiles_w * ncot;
+    int ns = 1;
+    while (ns < 8 && a.tiles_h % (2 * ns) == 0 && strips / (2 * ns) >= 256) ns *= 2;
+    if (a.tpb > 0 && a.tiles_h % a.tpb == 0) ns = a.tpb;           // explicit override (tests): tpb * 100 + cfg
+    a.tpb = ns;
+    dim3 grid(a.B * a.tiles_h * a.tiles_w / ns, ncot);
+    static const int xcd_env = [] { const char* e = getenv("LC_CONV_XCD"); return e ? atoi(e) : 1; }();
+    a.xcd = (xcd_env && grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
+    a.vert = 1;
+    {
+        const long long d = (const char*)a.wl - (const char*)a.wh;
+        if (d <= 0 || d >= (1ll << 31)) return LC_EINVAL;
+    }
+    const int gnm = a.gn ? (a.gn_silu ? 1 : 2) : 0;
+#define LC_PP_LAUNCH(E, G) hipLaunchKernelGGL((conv_f16x2_pp_kernel<E, G>), grid, dim3(PPG::NT), 0, st, a)
+    if (a.ostats && a.ounit == 2) {
+        if (gnm == 1) LC_PP_LAUNCH(2, 1); else if (gnm == 2) LC_PP_LAUNCH(2, 2); else LC_PP_LAUNCH(2, 0);
+    } else if (a.ostats) {
+        if (gnm == 1) LC_PP_LAUNCH(1, 1); else if (gnm == 2) LC_PP_LAUNCH(1, 2); else LC_PP_LAUNCH(1, 0);
+    } else {
+        if (gnm == 1) LC_PP_LAUNCH(0, 1); else if (gnm == 2) LC_PP_LAUNCH(0, 2); else LC_PP_LAUNCH(0, 0);
+    }
+#undef LC_PP_LAUNCH
+    return lc_launch_status();
+}
+
 template <int KS>
 int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
     switch (cfg) {
@@ -1736,6 +1738,7 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 23: return launch_pipe<HCfg<2, 4, 1, 2, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px (1x2)
         case 25: return launch_pipe<HCfg<2, 4, 1, 1, 2, 64, KS>>(a, st);  // 8 waves, 64 co x 128 px
         case 28: return launch_pipe<HCfg<1, 8, 1, 1, 4, 64, KS>>(a, st);  // 8 waves, 32 co x 256 px (Co <= 32)
+        case 33: return KS == 3 ? launch_pp(a, st) : LC_EUNSUP;           // ping-pong wave groups, 64 co x 256 px
         default: return LC_EUNSUP;
     }
 }
@@ -1752,6 +1755,7 @@ int pipe_stat_slots(int cfg, int H, int W) {
         case 23: th = 4; tw = 64; wpx = 4; break;
         case 25: th = 2; tw = 64; wpx = 4; break;
         case 28: th = 4; tw = 64; wpx = 8; break;
+        case 33: th = 4; tw = 64; wpx = 4; break;
         default: return 0;
     }
     return ((H + th - 1) / th) * ((W + tw - 1) / tw) * wpx;
@@ -1777,6 +1781,10 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     if (Ci >= 24) {    // 8-wave pipelined, persistent blocks: 230-333 TF when >= 1 block per CU
                        // exists (also the 32-channel input layer: 41 vs 70 us on the other kernel)
         if (Co <= 32 && t256 && blocks(64, 256) >= 256) return 28;   // output head (Co = 2)
+        // >= 2 strips per block of the ping-pong kernel: level-0 layers from batch 4
+        // (opt-in while it only matches the pipelined kernel: LC_PP_MIN_STRIPS=512; profiles/r04_pp_kernel.txt)
+        static const long long pp_min = [] { const char* e = getenv("LC_PP_MIN_STRIPS"); return e ? atoll(e) : 0ll; }();
+        if (pp_min > 0 && pp_eligible(Ci, Co, H, W, ks) && blocks(64, 256) >= pp_min) return 33;
         if (t256 && blocks(64, 256) >= 256) return 23;
         if (t128 && blocks(64, 128) >= 256) return 25;
         return 13;

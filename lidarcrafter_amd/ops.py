@@ -191,12 +191,12 @@ def set_conv_precision(mode: str) -> str:
 # buffer: of the base buffer, keyed by channel range), so a different tensor that later reuses the
 # same memory can never pick up stale statistics, and every wrapper that writes into an `out=`
 # tensor drops the statistics of what it overwrites.
-# DEFAULT OFF since the end of round 3: the statistics entry is a 128-bit store, and under the store pressure of the
-# deferred epilogue about one entry in 10^6 is written with a foreign dword (csrc/conv_f16x2.hip, DefEpi;
-# profiles/r03_conv_phases.txt) -- enough, now and then, to push a 50-step run past its tolerance.  The
-# statistics-pass route (one lc_groupnorm_stats launch per GroupNorm) has no such store and is bit-reproducible.
-# LC_GN_PRODUCER_STATS=1 turns the producer statistics back on (+3 % on C2, +5 % on C3 when they work).
-PRODUCER_GN_STATS = _os.environ.get("LC_GN_PRODUCER_STATS", "0") != "0"
+# Default ON again since round 4.  (End of round 3 it was switched off: the entry was ONE 128-bit buffer store with
+# an SGPR soffset, and ~3 entries in 10^7 arrived with a foreign upper dword under the store pressure of the deferred
+# epilogue.  The entry is now four 32-bit stores; devtools/entry_stress.py recomputes every entry of 10^8 per entry
+# unit: 0 off, against 17 in 5e7 for the old form on the same box -- profiles/r04_entry_store.txt.)
+# LC_GN_PRODUCER_STATS=0 selects the statistics-pass route (one lc_groupnorm_stats launch per GroupNorm).
+PRODUCER_GN_STATS = _os.environ.get("LC_GN_PRODUCER_STATS", "1") != "0"
 
 
 class _OctStatsHandle:

@@ -28,13 +28,11 @@ def golden():
     return load
 
 
-@pytest.fixture(autouse=True)
-def _producer_stats_where_tested(request, monkeypatch):
-    """Producer-side GroupNorm statistics are off by default (ops.PRODUCER_GN_STATS: open store hazard,
-    profiles/r03_conv_phases.txt); the tests that exercise them switch them on for themselves."""
-    name = request.node.name
-    if any(k in name for k in ("stats", "under_load", "producer", "split_k", "concat_segments", "groupnorm_split_matches",
-                                "presplit_vs_oracle")):
-        from lidarcrafter_amd import ops as K
-        monkeypatch.setattr(K, "PRODUCER_GN_STATS", True)
-    yield
+@pytest.fixture(params=[True, False], ids=["producer_stats", "stats_pass"])
+def gn_stats_route(request, monkeypatch):
+    """Both GroupNorm statistics routes, explicitly: entries emitted by the producing convolution (the default,
+    ops.PRODUCER_GN_STATS) and one lc_groupnorm_stats pass per GroupNorm (LC_GN_PRODUCER_STATS=0).  A test that
+    takes this fixture runs once per route; which route a test covers never depends on its name."""
+    from lidarcrafter_amd import ops as K
+    monkeypatch.setattr(K, "PRODUCER_GN_STATS", request.param)
+    return request.param

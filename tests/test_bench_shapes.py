@@ -52,7 +52,7 @@ def test_c2_forward_b8_golden(dev, golden, c2_ddpm):
     assert torch.allclose(y.flatten(1).norm(dim=1).cpu(), T(g["y_norm"]), rtol=1e-4)
 
 
-def test_c2_ddim50_b8_golden(dev, golden, c2_ddpm):
+def test_c2_ddim50_b8_golden(dev, golden, c2_ddpm, gn_stats_route):
     """Config C2 end to end: 50 DDIM steps at batch 8 through the graph-replayed sampler, CPU
     generators seeded with the sample index -- states 1 / 25 / 50 vs the reference's CPU run."""
     g = golden("c2_b8")
@@ -75,7 +75,7 @@ def test_c2_batch_vs_single_sample(dev, c2_ddpm):
     assert rel_l2(y1, y8[5:6]) < 5e-6
 
 
-def test_c3_b8_golden(dev, golden):
+def test_c3_b8_golden(dev, golden, gn_stats_route):
     """Config C3 shard: box-layout-v6 (LayoutUnetV1 70 M + layout encoder) at batch 8 -- forward and
     a 2-step DDIM run through the conditional sampler vs the reference."""
     from lidargen.utils import inference
