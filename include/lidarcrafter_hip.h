@@ -117,6 +117,13 @@ typedef struct lc_gn_stats_input {
     const lc_oct_stats *os0, *os1;               /* used when partials == NULL */
 } lc_gn_stats_input;
 
+/* Layout constraints of the pipelined tile configurations (12-28, 33; the configurations the heuristic picks for every
+ * 3x3 conv with Ci >= 24): they fetch both weight planes by LDS-DMA through ONE buffer descriptor, so wp_lo must lie
+ * ABOVE wp_hi at a distance below 2 GiB -- in practice one allocation holding both planes, which is what
+ * lc_pack_conv_weight_f16x2's callers in lidarcrafter_amd.ops make (LC_EINVAL otherwise); and a sample of the input,
+ * of the output and of the residual is addressed with 32-bit byte offsets: Ci*H*W*4, Co*H*W*4 < 2^31 (LC_EUNSUP).
+ * tile_cfg 33 = the ping-pong kernel (csrc/conv_f16x2_pp.h): 3x3, Ci % 16 == 0, 64 <= Ci <= 512, Co % 64 == 0,
+ * H % 4 == 0, W % 64 == 0 (LC_EUNSUP otherwise); the heuristic (tile_cfg 0) picks it only with LC_PP_MIN_STRIPS set. */
 int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, const void* wp_lo,
                              const float* bias, const float* res, int64_t res_bs, float* y,
                              int64_t y_bs, int B, int Ci, int Co, int H, int W, int ks,

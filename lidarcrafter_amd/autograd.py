@@ -47,9 +47,11 @@ def training_active(module: torch.nn.Module, *tensors) -> bool:
     """True when the caller expects an autograd graph: grad mode on and something requires grad."""
     if not torch.is_grad_enabled():
         return False
-    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        return True
-    return any(p.requires_grad for p in module.parameters())
+    active = any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors) or \
+        any(p.requires_grad for p in module.parameters())
+    if active:
+        K._range_defer.autograd_route = True      # tells ops.range_checked that this forward needs no poll
+    return active
 
 
 def _c4(t):
@@ -76,11 +78,15 @@ class ConvRing(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, holder):
         x = _c4(x)
+        x_rec = None
         if TRAIN_CONV_PRECISION == "f16x2":
             K.range_from_tensor(x, holder["fwd"])
+            # the record x was measured with, kept with the saved activation: the same module may run forward again
+            # (shared weights, two forwards feeding one loss) before this backward and re-measure the live record
+            x_rec = holder["fwd"].range_snapshot(x.device)
         y = K.conv2d_ring(x, holder["fwd"], weight, bias, precision=TRAIN_CONV_PRECISION)
         ctx.save_for_backward(x, weight)
-        ctx.holder, ctx.has_bias = holder, bias is not None
+        ctx.holder, ctx.has_bias, ctx.x_rec = holder, bias is not None, x_rec
         return y
 
     @staticmethod
@@ -108,11 +114,10 @@ class ConvRing(torch.autograd.Function):
             with torch.cuda.device(x.device):
                 st = torch.cuda.current_stream().cuda_stream
                 if w_split:
-                    # x's record is the one its forward conv split with (nothing re-measures it in
-                    # between: a module's backward follows its own forward)
+                    # x's record = the snapshot taken when its forward conv measured it
                     check(lib().lc_conv2d_ring_wgrad_f16x2(
                         x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy),
-                        ctx.holder["fwd"].range_ptr(x.device), ctx.holder["bwd"].range_ptr(x.device),
+                        ctx.x_rec.data_ptr(), ctx.holder["bwd"].range_ptr(x.device),
                         scratch.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), B, Ci,
                         Co, H, W, ks, 0, st), "lc_conv2d_ring_wgrad_f16x2")
                 else:

@@ -81,7 +81,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define LC_F16X2_TERMS 7
 #endif
 #if LC_TIMING
-__device__ unsigned long long lc_dbg[16];
+__device__ unsigned long long lc_dbg[32];
 #endif
 constexpr float X_PRESCALE_DEFAULT = 16.0f, W_PRESCALE_DEFAULT = 256.0f;
 
@@ -1652,6 +1652,7 @@ int launch_pipe(ConvArgsH a, hipStream_t st) {
     {   // the weight DMA addresses the lo plane through the hi plane's descriptor: one allocation
         const long long d = (const char*)a.wl - (const char*)a.wh;
         if (d <= 0 || d >= (1ll << 31)) return LC_EINVAL;
+        if (d + (long long)C::NTAP * a.Cib * a.Cop * 16 >= (1ll << 31)) return LC_EUNSUP;   // 32-bit offsets in the descriptor
     }
     const int gnm = a.gn ? (a.gn_silu ? 1 : 2) : 0;
 #define LC_PIPE_LAUNCH(E, G) hipLaunchKernelGGL((conv_f16x2_pipe_kernel<C, E, G>), grid, dim3(C::NT), 0, st, a)
@@ -1687,7 +1688,7 @@ int launch_h(ConvArgsH a, hipStream_t st) {
 
 // Ping-pong kernel (conv_f16x2_pp.h): shapes it takes, strips per block, launch.
 bool pp_eligible(int Ci, int Co, int H, int W, int ks) {
-    return ks == 3 && Ci % 32 == 0 && Ci >= 64 && Ci <= PPG::MAX_C && Co % 64 == 0 && H % 4 == 0 && W % 64 == 0;
+    return ks == 3 && Ci % 16 == 0 && Ci >= 64 && Ci <= PPG::MAX_C && Co % 64 == 0 && H % 4 == 0 && W % 64 == 0;
 }
 int launch_pp(ConvArgsH a, hipStream_t st) {
     if (!pp_eligible(a.Ci, a.Co, a.H, a.W, 3) || a.xsp || a.part) return LC_EUNSUP;
@@ -1709,6 +1710,7 @@ int launch_pp(ConvArgsH a, hipStream_t st) {
     {
         const long long d = (const char*)a.wl - (const char*)a.wh;
         if (d <= 0 || d >= (1ll << 31)) return LC_EINVAL;
+        if (d + (long long)PPG::NTAP * a.Cib * a.Cop * 16 >= (1ll << 31)) return LC_EUNSUP;
     }
     const int gnm = a.gn ? (a.gn_silu ? 1 : 2) : 0;
 #define LC_PP_LAUNCH(E, G) hipLaunchKernelGGL((conv_f16x2_pp_kernel<E, G>), grid, dim3(PPG::NT), 0, st, a)
@@ -1946,6 +1948,8 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
         return LC_EINVAL;
     if (ks != 1 && ks != 3) return LC_EUNSUP;
     if ((long long)H * W >= (1 << 24)) return LC_EUNSUP;
+    // the kernels address a sample with 32-bit byte offsets (0x80000000 is their out-of-range marker)
+    if ((long long)Ci * H * W * 4 >= (1ll << 31) || (long long)Co * H * W * 4 >= (1ll << 31)) return LC_EUNSUP;
     ConvArgsH a;
     a.x = x; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
     a.y = y; a.x_bs = x_bs; a.res_bs = res_bs; a.y_bs = y_bs;
@@ -2004,8 +2008,8 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
 #if LC_TIMING
 extern "C" int lc_debug_read(unsigned long long* out16, int reset) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out16, HIP_SYMBOL(lc_dbg), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(lc_dbg), z, sizeof(z)); }
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(lc_dbg), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(lc_dbg), z, sizeof(z)); }
     return 0;
 }
 #endif

@@ -347,6 +347,7 @@ import threading as _threading
 
 class _Defer(_threading.local):
     depth = 0
+    autograd_route = False      # set by autograd.training_active when a forward takes the training graph
 
 
 _range_defer = _Defer()          # per thread: a sampler thread's deferral does not silence another's
@@ -560,14 +561,16 @@ def range_checked(forward):
         if _range_defer.depth > 0 or CONV_PRECISION != "f16x2" or not isinstance(x, torch.Tensor) or \
                 not x.is_cuda or torch.cuda.is_current_stream_capturing():
             return forward(self, *args, **kw)
-        if torch.is_grad_enabled() and (x.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
-            # training graph: every operand's pre-scale is measured on the device right before
-            # its conv (range_from_tensor), so nothing can be invalid -- and a poll would be a
-            # blocking device->host copy per step, a retry a second graph with new dropout masks
-            return forward(self, *args, **kw)
         for _ in range(5):
+            _range_defer.autograd_route = False
             out = forward(self, *args, **kw)
+            if _range_defer.autograd_route:
+                # the forward took the training graph (autograd.training_active said so AND the forward acted on
+                # it): every operand's pre-scale was measured on the device right before its conv
+                # (range_from_tensor), nothing can be invalid -- and a poll would be a blocking device->host copy per
+                # step, a retry a second graph with new dropout masks.  A grad-mode call that ran the INFERENCE
+                # kernels (precomputed time_features) is polled like any other.
+                return out
             bad = range_poll(x.device)
             if not bad:
                 return out
@@ -633,6 +636,14 @@ class PackedConv:
 
     def __reduce__(self):
         return (PackedConv, (self.name,))
+
+    def range_snapshot(self, device) -> torch.Tensor:
+        """A private 16-byte copy of this layer's range record as it is NOW on the stream (training: the record the
+        forward conv of a saved activation split with -- a second forward of the same module before the backward
+        re-measures the live record, and the weight-gradient kernel must split the saved x with the scale that was
+        measured for IT)."""
+        self.range_ptr(device)
+        return self._arena.buf[self._slot].clone()
 
     def range_ptr(self, device) -> int:
         if self._arena is None or self._arena.device != device:

@@ -47,6 +47,35 @@ def test_conv_gradients(dev, B, Ci, Co, H, W, ks):
     assert rel_l2(m.bias.grad, br.grad) < 2e-6
 
 
+def test_shared_conv_two_forwards_one_backward(dev):
+    """One module applied twice, to inputs 2000x apart in magnitude, before a single backward: each saved activation is
+    split by the weight-gradient kernel with the range record that was measured for IT (autograd.ConvRing keeps a
+    snapshot), not with whatever the module's live record holds after the second forward."""
+    from lidarcrafter_amd import autograd as AG
+    from oracle import denoiser as D
+
+    B, C, H, W = 2, 64, 8, 64
+    x1 = seeded_randn(B, C, H, W, seed=71) * 900.0
+    x2 = seeded_randn(B, C, H, W, seed=72) * 0.4
+    w = seeded_randn(C, C, 3, 3, seed=73) / (C * 9) ** 0.5
+    b = seeded_randn(C, seed=74)
+    g1, g2 = seeded_randn(B, C, H, W, seed=75), seeded_randn(B, C, H, W, seed=76)
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ((D.conv_ring(x1, wr, br) * g1).sum() + (D.conv_ring(x2, wr, br) * g2).sum()).backward()
+
+    class M:
+        pass
+
+    m = M()
+    m.weight, m.bias = w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    y1 = AG.conv(m, x1.to(dev))
+    y2 = AG.conv(m, x2.to(dev))
+    ((y1 * g1.to(dev)).sum() + (y2 * g2.to(dev)).sum()).backward()
+    assert torch.isfinite(m.weight.grad).all()
+    assert rel_l2(m.weight.grad, wr.grad) < 2e-6, rel_l2(m.weight.grad, wr.grad)
+    assert rel_l2(m.bias.grad, br.grad) < 2e-6
+
+
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(8, 64, 64, 32, 1024, 3), (4, 128, 64, 16, 512, 3), (2, 192, 128, 8, 256, 1),
                                             (1, 34, 64, 32, 1024, 3), (2, 64, 2, 32, 1024, 3)])
 def test_split_weight_gradient_vs_exact_fp32(dev, B, Ci, Co, H, W, ks):
