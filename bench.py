@@ -87,8 +87,17 @@ def cpu_baseline(n_steps: int = 2):
     for i in range(n_steps):
         x = DF.p_step(den, x, steps[:, i], steps[:, i + 1], noise, mode="ddim")
     dt = time.perf_counter() - t0
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": n_steps / dt, "unit": "denoising-steps/s (batch 8)",
-            "cores": torch.get_num_threads(), "kind": "port",
+            "cores": torch.get_num_threads(), "cpu_model": cpu_model, "kind": "port",
             "sample": f"{n_steps} DDIM steps of the C2 batch (8x 32x1024) through "
                       f"oracle.efficient_unet_forward + oracle p_step, torch fp32 CPU, "
                       f"{dt:.1f} s wall"}
@@ -386,6 +395,10 @@ def main():
                        "graph_setup_steps": setup,
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
                        "resolution": list(RES), "parallelism": f"dp{world} (no data-path collective)",
+                       "rng": "x_T from per-sample CPU generators (global sample index); the timed DDIM steps run with "
+                              "rng=None (eta = 0 uses no noise).  The parity mode -- a CPU generator per sample, "
+                              "advanced every step as the reference does -- is timed as a row of its own: "
+                              "devtools/bench_rows.py uncond_32x1024_cpu_generators (profiles/r04_rows.json)",
                        "sample_steps_per_s": round(steps_per_s * BATCH_PER_GPU, 2),
                        "algorithmic_tflops": round(
                            steps_per_s * BATCH_PER_GPU * GFLOP_PER_SAMPLE_STEP / 1e3, 2)},

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
-GFLOP = {"uncond32": 116.6, "uncond64": 476.5, "cond32": 255.9}   # SURVEY 8(d), per sample-step
+GFLOP = {"uncond32": 116.6, "uncond64": 476.5, "cond32": 255.9, "cond64": 1468.9}   # SURVEY 8(d), per sample-step
 
 
 def timed(fn, n, warm=2):
@@ -126,6 +126,120 @@ def cond(dev, B, steps):
             "layout_encoder_first_call_ms": round(t_first * 1e3, 2)}
 
 
+def _cond_pair_64(cond_out):
+    """The full-width architecture of nuscenes-box-layout-v6 (cond_out 10) / nuscenes-auto-reg-v2 (11 condition
+    channels) at 64 x 2048 -- the constructor arguments of those configs with the C4 resolution."""
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.models.unets import __all__ as U
+    from lidargen.utils.lidar import get_linear_ray_angles
+
+    res = (64, 2048)
+    m = U["layout_unet_v1"](
+        in_channels=2 + cond_out, resolution=res, image_size=64, use_fp16=False, use_scale_shift_norm=True,
+        out_channels=2, model_channels=64, encoder_channels=64, num_head_channels=32, num_heads=-1,
+        num_heads_upsample=-1, num_res_blocks=2, num_attention_blocks=1, resblock_updown=True, attention_ds=[4, 8],
+        channel_mult=[1, 2, 4, 8], dropout=0.1, use_checkpoint=False, use_positional_embedding_for_attention=True,
+        attention_block_type="ObjectAwareCrossAttention")
+    m.coords = get_linear_ray_angles(res[0], res[1], 10.0, -30.0)
+    enc = U["layout_encoder"](
+        feature_map_size=list(res), used_condition_types=["obj_class", "obj_bbox", "is_valid_obj"], layout_length=13,
+        num_classes_for_layout_object=9, mask_size_for_layout_object=32, hidden_dim=64, output_dim=256, num_layers=6,
+        num_heads=4, use_final_ln=True, use_positional_embedding=False, not_use_layout_fusion_module=False,
+        resolution_to_attention=[4, 8], use_key_padding_mask=False, out_channels=cond_out)
+    return seeded_fill(m, salt=200).eval(), seeded_fill(enc, salt=201).eval()
+
+
+def cond64(dev, B, steps):
+    """The denoising step of config C4's frames 1..4: nuscenes-auto-reg-v2 architecture (LayoutUnetV1, 11 condition
+    channels, object-aware cross attention over 8192 + 13 and 2048 + 13 keys) at 64 x 2048, DDPM."""
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+
+    m, enc = _cond_pair_64(11)
+    ddpm = CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval().to(dev)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(B, 64, 2048, seed=91, n_extra=1).items()}
+    rng = [torch.Generator().manual_seed(i) for i in range(B)]
+    with torch.inference_mode():
+        x_T = ddpm.randn(B, *ddpm.sampling_shape, rng=rng, device=ddpm.device)
+        cdict = ddpm.get_network_condition(input_dict=batch, only_custom_condition=True)
+        st = ddpm.begin_sampling(B, steps + 3, None, "ddpm", 0.0, x_T=x_T, condition_dict=cdict)
+        dt = timed(lambda: ddpm.sampling_step(st), steps, warm=3)
+        x = st["x"]
+    assert torch.isfinite(x).all()
+    return {"batch": B, "resolution": [64, 2048], "mode": "ddpm (device noise)", "ms_per_step": round(dt * 1e3, 3),
+            "steps_per_s": round(1 / dt, 2), "sample_steps_per_s": round(B / dt, 1),
+            "algorithmic_tflops": round(B * GFLOP["cond64"] / dt / 1e3, 1),
+            "frac_of_f16_mfma_peak": round(B * GFLOP["cond64"] / dt / 1e3 / 2500.0, 4)}
+
+
+def sequence64(dev, frames, steps):
+    """Config C4 itself at B = 1: frame 0 with the box-layout-v6 architecture, frames 1.. with auto-reg-v2, both at
+    64 x 2048, DDPM with the per-sample CPU generator (the parity mode), temporal glue on the device."""
+    import numpy as np
+    from lidarcrafter_amd.testing import synth_scene_boxes, synth_temporal_inputs
+    from lidargen.dataset.custom_dataset import CustomDataset, DataConfig
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from lidargen.utils import temporal
+    from lidargen.utils.lidar import LiDARUtility
+
+    H, W = 64, 2048
+    m0, e0 = _cond_pair_64(10)
+    m1, e1 = _cond_pair_64(11)
+    ddpm = CondContinuousTimeGaussianDiffusion(m0, e0, cond_mode="concat").eval().to(dev)
+    auto = CondContinuousTimeGaussianDiffusion(m1, e1, cond_mode="concat").eval().to(dev)
+    lu = LiDARUtility(resolution=(H, W), depth_format="log_depth", min_depth=1.45, max_depth=80.0,
+                      ray_angles=m0.coords).to(dev)
+
+    class Cfg(DataConfig):
+        resolution = (H, W)
+
+    K_ = 6
+    sb = synth_scene_boxes(K_, seed=40)
+    names = ["ego"] + [DataConfig.class_names[int(c) - 1] for c in sb[:, 7]]
+    info = dict(gt_boxes=np.concatenate([np.zeros((1, 7)), sb[:, :7].astype(np.float64)]), gt_names=names)
+    ds = CustomDataset([dict(info)], cfg=Cfg())
+    batch = ds.collate_fn([ds[0]])
+    batch["gt_fut_trajs"] = [synth_temporal_inputs(50, K=K_)[0]]
+
+    def run(nf, ns):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fr, _ = temporal.generate_sequence(ddpm, auto, lu, dict(batch), num_frames=nf, num_steps=ns, mode="ddpm",
+                                           traj_length=16, rng=[torch.Generator().manual_seed(90)], data_cfg=Cfg())
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(f).all() for f in fr)
+        return time.perf_counter() - t0
+
+    run(2, 4)
+    t_full = run(frames, steps)
+    t_glue = run(frames, 3)
+    per_step = (t_full - t_glue) / (frames * (steps - 3))
+    return {"batch": 1, "frames": frames, "resolution": [H, W], "steps_per_frame": steps, "mode": "ddpm, CPU generator",
+            "seconds": round(t_full, 3), "ms_per_denoising_step": round(per_step * 1e3, 3),
+            "algorithmic_tflops": round(GFLOP["cond64"] / per_step / 1e3, 1),
+            "frac_of_f16_mfma_peak": round(GFLOP["cond64"] / per_step / 1e3 / 2500.0, 4),
+            "glue_ms_per_frame_upper_bound": round((t_glue - 3 * frames * per_step) / frames * 1e3, 2)}
+
+
+def uncond_generators(dev, B, steps, mode):
+    """C2 with the per-sample CPU-generator list every parity test uses (bench.py times rng=None): the draws of a step
+    are made on the host, staged in pinned memory and copied once per step (DDPM; DDIM eta = 0 only ADVANCES the
+    generators, as the reference does)."""
+    from lidarcrafter_amd.testing import seeded_fill
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model, _ = inference.load_model_duffusion_training(C["nuscenes-unet-uncond"]())
+    seeded_fill(model, salt=100)
+    ddpm = ddpm.eval().to(dev)
+    rng = [torch.Generator().manual_seed(i) for i in range(B)]
+    st = ddpm.begin_sampling(B, steps + 3, rng=rng, mode=mode, ddim_eta=0.0)
+    dt = timed(lambda: ddpm.sampling_step(st), steps, warm=3)
+    assert torch.isfinite(st["x"]).all()
+    return {"batch": B, "mode": mode, "rng": "one CPU torch.Generator per sample (parity mode)",
+            "ms_per_step": round(dt * 1e3, 3), "steps_per_s": round(1 / dt, 2)}
+
+
 def sequence(dev, B, frames, steps):
     """C4-shaped run at 32x1024: frame 0 with nuscenes-box-layout-v6, frames 1.. with
     nuscenes-auto-reg-v2 (DDPM), the temporal glue resident on the device."""
@@ -224,7 +338,7 @@ def projection(dev, N):
     algo = 16 * N + 8 * N + 24 * H * W
     return {"points": N, "us": round(dt * 1e6, 1), "algorithmic_bytes": algo,
             "GBps": round(algo / dt / 1e9, 1), "frac_of_hbm_peak": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "includes the wrapper's three torch.empty allocations; latency-bound at this size"}
+            "note": "two launches (scatter, gather that re-empties the cached z-buffer) + the image / winner allocations"}
 
 
 def pib(dev, N, nbox):
@@ -353,6 +467,9 @@ def main():
                                    for B in ((1, 8) if q else (1, 2, 8, 32))],
         "cond_layout_v6_32x1024": lambda: [cond(dev, B, 10) for B in ((8,) if q else (1, 8))],
         "uncond_64x2048": lambda: [] if q else [uncond(dev, 4, (64, 2048), 6, "uncond64")],
+        "cond_autoreg_v2_64x2048": lambda: [cond64(dev, B, 6) for B in ((1,) if q else (1, 2))],
+        "temporal_sequence_c4_64x2048": lambda: [sequence64(dev, 5, 8 if q else 16)],
+        "uncond_32x1024_cpu_generators": lambda: [uncond_generators(dev, 8, 20, m) for m in ("ddim", "ddpm")],
         "uncond_32x1024_fp16_autocast_single_product": lambda: [uncond_autocast(dev, 8, 20)],
         "temporal_sequence_32x1024": lambda: [sequence(dev, 2, 5, 16 if q else 32)],
         "pipeline_metrics_c5_shape": lambda: [pipeline_metrics(dev, 8, 1 if q else 2, 8)],

@@ -90,6 +90,8 @@ SIGNATURES = {
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),
     "lc_add_scale": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, f32, vp]),
     "lc_project_points": (i32, [vp, i32, i32, i32, f64, f64, f32, f32, vp, vp, vp, vp, i32, vp]),
+    "lc_project_workspace_init": (i32, [vp, i32, vp]),
+    "lc_project_points_ws": (i32, [vp, i32, i32, i32, f64, f64, f32, f32, vp, vp, vp, vp, i32, vp]),
     "lc_project_points_f64": (i32, [vp, i32, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp]),
     "lc_range_postprocess": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "lc_condition_preprocess": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, f32, vp]),

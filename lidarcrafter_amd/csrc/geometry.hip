@@ -58,14 +58,18 @@ __global__ __launch_bounds__(256) void project_scatter_kernel(const float* __res
     atomicMin(zb + (long long)gh * W + gw, key);
 }
 
+// RESET: the cell is handed back empty (~0), so a caller-owned z-buffer needs no clear launch before the
+// next projection (lc_project_points_ws)
+template <bool RESET>
 __global__ __launch_bounds__(256) void project_gather_kernel(const float* __restrict__ pts, int HW,
-                                                            const unsigned long long* __restrict__ zb,
+                                                            unsigned long long* __restrict__ zb,
                                                             float min_d, float max_d,
                                                             float* __restrict__ img,
                                                             int* __restrict__ winner) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= HW) return;
     const unsigned long long key = zb[c];
+    if (RESET) zb[c] = ~0ull;
     float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int win = -1;
     if (key != ~0ull) {
@@ -230,7 +234,37 @@ extern "C" int lc_project_points(const float* points, int N, int H, int W, doubl
             hipLaunchKernelGGL(project_scatter_kernel<false>, dim3((N + 255) / 256), dim3(256), 0,
                                lc_s(s), points, N, H, W, h_up, h_down, zb, cells);
     }
-    hipLaunchKernelGGL(project_gather_kernel, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
+    hipLaunchKernelGGL(project_gather_kernel<false>, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
+                       HW, zb, min_depth, max_depth, image, winner);
+    return lc_launch_status();
+}
+
+extern "C" int lc_project_workspace_init(uint64_t* zbuf, int n_cells, lc_stream_t s) {
+    if (!zbuf || n_cells <= 0) return LC_EINVAL;
+    hipLaunchKernelGGL(zbuf_clear_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, lc_s(s),
+                       reinterpret_cast<unsigned long long*>(zbuf), n_cells);
+    return lc_launch_status();
+}
+
+extern "C" int lc_project_points_ws(const float* points, int N, int H, int W, double fov_up_deg,
+                                    double fov_down_deg, float min_depth, float max_depth,
+                                    uint64_t* zbuf, float* image, int32_t* winner, int32_t* cells,
+                                    int elev_f64, lc_stream_t s) {
+    if ((!points && N > 0) || !zbuf || !image || N < 0 || H <= 0 || W <= 0) return LC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(points) & 15) return LC_EINVAL;
+    const int HW = H * W;
+    const double h_up = fov_up_deg * 0.017453292519943295;
+    const double h_down = fov_down_deg * 0.017453292519943295;
+    auto zb = reinterpret_cast<unsigned long long*>(zbuf);
+    if (N > 0) {
+        if (elev_f64)
+            hipLaunchKernelGGL(project_scatter_kernel<true>, dim3((N + 255) / 256), dim3(256), 0,
+                               lc_s(s), points, N, H, W, h_up, h_down, zb, cells);
+        else
+            hipLaunchKernelGGL(project_scatter_kernel<false>, dim3((N + 255) / 256), dim3(256), 0,
+                               lc_s(s), points, N, H, W, h_up, h_down, zb, cells);
+    }
+    hipLaunchKernelGGL(project_gather_kernel<true>, dim3((HW + 255) / 256), dim3(256), 0, lc_s(s), points,
                        HW, zb, min_depth, max_depth, image, winner);
     return lc_launch_status();
 }

@@ -1243,6 +1243,9 @@ def add_scale(a: torch.Tensor, b: torch.Tensor, scale: float, out=None) -> torch
 PROJECTION_DTYPE = _os.environ.get("LC_PROJECTION_DTYPE", "native")
 
 
+_proj_ws = {}
+
+
 def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down: float,
                    min_depth: float, max_depth: float, return_cells: bool = False,
                    dtype_mode: Optional[str] = None):
@@ -1271,15 +1274,24 @@ def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down
         raise ValueError("project_points: points must be contiguous [N,4]")
     N = points.shape[0]
     dev = points.device
-    zbuf = torch.empty(H * W, device=dev, dtype=torch.int64)
+    # z-buffer: one per (device, stream, H * W), emptied once; every projection hands it back empty
+    # (lc_project_points_ws): two launches and no scratch allocation per call
+    st = _stream()
+    key = (dev, st, H * W)
+    zbuf = _proj_ws.get(key)
+    if zbuf is None:
+        with torch.inference_mode(False):
+            zbuf = torch.empty(H * W, device=dev, dtype=torch.int64)
+        check(lib().lc_project_workspace_init(zbuf.data_ptr(), H * W, st), "lc_project_workspace_init")
+        _proj_ws[key] = zbuf
     img = torch.empty((H, W, 6), device=dev, dtype=_F32)
     win = torch.empty((H, W), device=dev, dtype=torch.int32)
     cells = torch.empty((N, 2), device=dev, dtype=torch.int32) if return_cells else None
-    check(lib().lc_project_points(points.data_ptr(), N, H, W, float(fov_up), float(fov_down),
-                                  float(min_depth), float(max_depth), zbuf.data_ptr(),
-                                  img.data_ptr(), win.data_ptr(), _p(cells),
-                                  1 if mode == "native" else 0, _stream()),
-          "lc_project_points")
+    check(lib().lc_project_points_ws(points.data_ptr(), N, H, W, float(fov_up), float(fov_down),
+                                     float(min_depth), float(max_depth), zbuf.data_ptr(),
+                                     img.data_ptr(), win.data_ptr(), _p(cells),
+                                     1 if mode == "native" else 0, st),
+          "lc_project_points_ws")
     return (img, win, cells) if return_cells else (img, win)
 
 
