@@ -280,6 +280,24 @@ int lc_attention_f16x2_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
                            int64_t o_bs, int64_t o_hs, int64_t o_cs, int B, int heads, int Lq,
                            int Lk0, int Lk1, int dqk, int dpos, int dv, float scale,
                            lc_stream_t s);
+/* ---------------------------------------------------------------------------------------------
+ * Training: the same attention with a backward pass, so that loss.backward() never materialises
+ * the [B*heads, Lq, Lk] scores or their gradient (autograd of nn.MultiheadAttention efficient_unet.py:28-58 and
+ * of ObjectAwareCrossAttention.forward layout_unet_v1.py:489-506 as tools/train/train_lidm_cond.py:259-322 runs
+ * them; softmax in fp32, layout_unet_v1.py:502).  Plain operands: heads back to back, per head a [d, L] matrix
+ * with L contiguous -- q [BH, dqk, Lq], k [BH, dqk, Lk], v [BH, dv, Lk], o / do [BH, dv, Lq]; the caller
+ * concatenates content / positional channels and image / layout keys (lidarcrafter_amd/autograd.py).
+ * lc_attention_train_fwd = lc_attention_fwd (f16x2 = 0) or lc_attention_f16x2_fwd (1) + lse [BH, Lq]: the
+ * log2-sum-exp of the scaled scores per query.  lc_attention_bwd recomputes P = exp2(S - lse) tile by tile in
+ * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and writes dq, dk, dv (same shapes as q, k, v); deterministic (one
+ * kernel with the queries as the outer dimension for dq, one with the keys for dk / dv; no atomics).
+ * dsum_scratch: float [BH, Lq].  dqk, dv <= 64.
+ * ------------------------------------------------------------------------------------------- */
+int lc_attention_train_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int BH, int Lq,
+                           int Lk, int dqk, int dv, float scale, int f16x2, lc_stream_t s);
+int lc_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                     const float* lse, float* dsum_scratch, float* dq, float* dk, float* dv, int BH, int Lq, int Lk,
+                     int dqk, int dv_ch, float scale, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse-diffusion update, one fused elementwise pass:

@@ -43,6 +43,13 @@ TRAIN_CONV_PRECISION = os.environ.get("LC_TRAIN_CONV_PRECISION", "f16x2")
 TRAIN_WGRAD_PRECISION = os.environ.get("LC_TRAIN_WGRAD_PRECISION", "f16x2")
 
 
+# Attention of the training graph: "hip" = flash forward (f16x2 split, + log2-sum-exp) and exact-fp32 MFMA backward
+# (csrc/attention.hip, attention_bwd.hip: no score matrix in HBM, deterministic); "torch" = einsum / softmax over
+# materialised scores (the round-2/3 route; kept for A/B and for heads wider than 64 channels).
+TRAIN_ATTENTION = os.environ.get("LC_TRAIN_ATTENTION", "hip")
+TRAIN_ATTN_FWD_PRECISION = os.environ.get("LC_TRAIN_ATTN_FWD_PRECISION", "f16x2")
+
+
 def training_active(module: torch.nn.Module, *tensors) -> bool:
     """True when the caller expects an autograd graph: grad mode on and something requires grad."""
     if not torch.is_grad_enabled():
@@ -136,6 +143,52 @@ def conv(module, x):
         module.__dict__["_train_packed"] = holder
     w = module.weight if module.weight.dim() == 4 else module.weight[:, :, :, None]
     return ConvRing.apply(x, w, module.bias, holder)
+
+
+class FlashAttention(torch.autograd.Function):
+    """o[b,h,c,t] = sum_s softmax_s(scale * sum_c' q[b,h,c',t] k[b,h,c',s]) v[b,h,c,s] for channel-major operands
+    q [B,h,dqk,Lq], k [B,h,dqk,Lk], v [B,h,dv,Lk] (dqk, dv <= 64).  nn.MultiheadAttention of SelfAttentionBlock
+    (efficient_unet.py:28-58) and ObjectAwareCrossAttention.forward (layout_unet_v1.py:489-506) with the content /
+    positional channels and the image / layout keys concatenated by the caller."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        q, k, v = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
+        B, h, dqk, Lq = q.shape
+        Lk, dv = k.shape[-1], v.shape[2]
+        o = torch.empty((B, h, dv, Lq), device=q.device, dtype=torch.float32)
+        lse = torch.empty((B * h, Lq), device=q.device, dtype=torch.float32)
+        with torch.cuda.device(q.device):
+            check(lib().lc_attention_train_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(),
+                                               B * h, Lq, Lk, dqk, dv, float(scale),
+                                               1 if TRAIN_ATTN_FWD_PRECISION == "f16x2" else 0,
+                                               torch.cuda.current_stream().cuda_stream), "lc_attention_train_fwd")
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do.contiguous().float()
+        B, h, dqk, Lq = q.shape
+        Lk, dv = k.shape[-1], v.shape[2]
+        dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        scratch = torch.empty((B * h, Lq), device=q.device, dtype=torch.float32)
+        with torch.cuda.device(q.device):
+            check(lib().lc_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
+                                         lse.data_ptr(), scratch.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                         dvv.data_ptr(), B * h, Lq, Lk, dqk, dv, ctx.scale,
+                                         torch.cuda.current_stream().cuda_stream), "lc_attention_bwd")
+        return dq, dk, dvv, None
+
+
+def flash_attention(q, k, v, scale):
+    """The training graph's attention core (see FlashAttention); torch ops when switched off or out of range."""
+    if TRAIN_ATTENTION == "hip" and q.is_cuda and q.shape[2] <= 64 and v.shape[2] <= 64:
+        return FlashAttention.apply(q, k, v, scale)
+    w = (torch.einsum("bhct,bhcs->bhts", q, k) * scale).softmax(-1)
+    return torch.einsum("bhts,bhcs->bhct", w, v)
 
 
 class GroupNormAct(torch.autograd.Function):
@@ -253,8 +306,7 @@ def efficient_unet_forward(m, images: torch.Tensor, log_snr: torch.Tensor) -> to
         q = conv(_LinearAsConv(sa.attn.in_proj_weight, sa.attn.in_proj_bias, sa, "in"),
                  group_norm(sa.norm, x))
         q = q.view(B_, 3, heads, C // heads, H * W)
-        s = torch.einsum("bhct,bhcs->bhts", q[:, 0], q[:, 1]) * (C // heads) ** -0.5
-        o = torch.einsum("bhts,bhcs->bhct", s.softmax(-1), q[:, 2]).reshape(B_, C, H, W)
+        o = flash_attention(q[:, 0], q[:, 1], q[:, 2], (C // heads) ** -0.5).reshape(B_, C, H, W)
         o = conv(_LinearAsConv(sa.attn.out_proj.weight, sa.attn.out_proj.bias, sa, "out"), o)
         return (x + o) * sa._scale_f
 
@@ -367,11 +419,11 @@ def layout_unet_v1_forward(m, x: torch.Tensor, cond_dict: dict) -> torch.Tensor:
         q, k, v = (hv(t_) for t_ in qkv.split(C, dim=1))
         pi, pl, kl, vl = hv(pos_img), hv(pos_lay), hv(kv[:, :C]), hv(kv[:, C:])
         s2 = 1.0 / (2 * d) ** 0.5                     # (q s)(k s) with s = (2d)^-1/4
-        # content and positional halves of the concatenated operands contribute separate products
-        s_img = (torch.einsum("bhct,bhcs->bhts", q, k) + torch.einsum("bhct,bhcs->bhts", pi, pi)) * s2
-        s_lay = (torch.einsum("bhct,bhcs->bhts", q, kl) + torch.einsum("bhct,bhcs->bhts", pi, pl)) * s2
-        w = torch.cat([s_img, s_lay], dim=-1).softmax(-1)
-        a = torch.einsum("bhts,bhcs->bhct", w[..., :L1], v) + torch.einsum("bhts,bhcs->bhct", w[..., L1:], vl)
+        # the concatenated operands of layout_unet_v1.py:453-454,476-480: channels = content ++ positional,
+        # keys = image tokens ++ the 13 layout tokens
+        a = flash_attention(torch.cat([q, pi], dim=2),
+                            torch.cat([torch.cat([k, pi], dim=2), torch.cat([kl, pl], dim=2)], dim=3),
+                            torch.cat([v, vl], dim=3), s2)
         out = xs + _conv_tok(at.proj_out, a.reshape(B_, C, L1))
         return out.reshape(B_, C, H_, W_)
 

@@ -24,6 +24,7 @@ struct AttnArgs {
     long long o_bs, o_hs, o_cs;
     int heads, Lq, Lk0, Lk1, dqk, dpos, dv;
     float qscale;  // scale * log2(e)
+    float* lse;    // optional [B * heads, Lq]: log2-sum-exp of the scaled scores (base 2, qscale included) for the backward pass
 };
 
 __device__ __forceinline__ const float* head_ptr(const lc_cm_operand& x, int b, int h) {
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     float* op = a.o + b * a.o_bs + h * a.o_hs;
+    if (a.lse && t < a.Lq && kh == 0) a.lse[(long long)bh * a.Lq + t] = m_run + log2f(l_tot);
     if (t < a.Lq) {
 #pragma unroll
         for (int i = 0; i < NDV; ++i)
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / (l_tot * V_PRE);
     float* op = a.o + b * a.o_bs + h * a.o_hs;
+    if (a.lse && t < a.Lq && kh == 0) a.lse[(long long)bh * a.Lq + t] = m_run + log2f(l_tot) - P_LOG2;   // (l_run carries P_PRE)
     if (t < a.Lq) {
 #pragma unroll
         for (int i = 0; i < NDV; ++i)
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
 
 }  // namespace
 
-static int attention_launch(int split, const lc_cm_operand* q, const lc_cm_operand* q_pos,
+static int attention_launch(int split, float* lse, const lc_cm_operand* q, const lc_cm_operand* q_pos,
                                 const lc_cm_operand* k, const lc_cm_operand* k_pos,
                                 const lc_cm_operand* v, const lc_cm_operand* k2,
                                 const lc_cm_operand* k2_pos, const lc_cm_operand* v2, float* o,
@@ -446,6 +449,7 @@ static int attention_launch(int split, const lc_cm_operand* q, const lc_cm_opera
     a.o = o; a.o_bs = o_bs; a.o_hs = o_hs; a.o_cs = o_cs;
     a.heads = heads; a.Lq = Lq; a.Lk0 = Lk0; a.Lk1 = Lk1; a.dqk = dqk; a.dpos = dpos; a.dv = dv;
     a.qscale = scale * 1.4426950408889634f;
+    a.lse = lse;
     dim3 grid((Lq + 127) / 128, B * heads);
     const int dq = (dqk + dpos) <= 32 ? 32 : 64, nd = dv <= 32 ? 1 : 2;
     if (split && dqk % 8 == 0) {   // (a K unit = 8 channels of ONE operand; else the fp32 kernel)
@@ -472,5 +476,13 @@ static int attention_launch(int split, const lc_cm_operand* q, const lc_cm_opera
     q, q_pos, k, k_pos, v, k2, k2_pos, v2, o, o_bs, o_hs, o_cs, B, heads, Lq, Lk0, Lk1, dqk,     \
         dpos, dv, scale, s
 
-extern "C" int lc_attention_fwd(LC_ATTN_PARAMS) { return attention_launch(0, LC_ATTN_ARGS); }
-extern "C" int lc_attention_f16x2_fwd(LC_ATTN_PARAMS) { return attention_launch(1, LC_ATTN_ARGS); }
+extern "C" int lc_attention_fwd(LC_ATTN_PARAMS) { return attention_launch(0, nullptr, LC_ATTN_ARGS); }
+extern "C" int lc_attention_f16x2_fwd(LC_ATTN_PARAMS) { return attention_launch(1, nullptr, LC_ATTN_ARGS); }
+// Training forward: the same kernels, plus the per-query log2-sum-exp the backward pass recomputes P from
+extern "C" int lc_attention_train_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int BH,
+                                      int Lq, int Lk, int dqk, int dv, float scale, int f16x2, lc_stream_t s) {
+    if (!q || !k || !v || !o || !lse || BH <= 0) return LC_EINVAL;
+    const lc_cm_operand oq = {q, (int64_t)dqk * Lq, 0, Lq}, ok = {k, (int64_t)dqk * Lk, 0, Lk}, ov = {v, (int64_t)dv * Lk, 0, Lk};
+    return attention_launch(f16x2, lse, &oq, nullptr, &ok, nullptr, &ov, nullptr, nullptr, nullptr, o, (int64_t)dv * Lq, 0, Lq,
+                            BH, 1, Lq, Lk, 0, dqk, 0, dv, scale, s);
+}
