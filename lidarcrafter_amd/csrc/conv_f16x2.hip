@@ -67,6 +67,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef LC_PIPE_ROWS
 #define LC_PIPE_ROWS 1  // fused-GroupNorm rows are read ahead of the tap's fragment fetch (no lgkmcnt(0) drain)
 #endif
+#ifndef LC_DMA_FIRST
+#define LC_DMA_FIRST 0   // pipelined kernel: 1 = the chunk's weight-DMA pieces are issued in front of its deferred-epilogue slots
+#endif
 #ifndef LC_TIMING
 #define LC_TIMING 0     // developer build: s_memtime phase totals of the fp32-input pipelined kernel -> lc_dbg
 #endif
@@ -1065,6 +1068,15 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
             }
         };
         fetch(0, 0);
+#if LC_DMA_FIRST
+        // All weight-DMA pieces of the chunk go out BEFORE its first deferred-epilogue slot: VMEM returns in order, so a
+        // piece issued behind a tap's stores (one per tap, the round-3 placement) makes the wait in front of the chunk
+        // barrier a wait for those stores' acknowledgements -- in the fourth peeled chunk of a tile a vmcnt(0).
+        if (NTAP != 1) {
+#pragma unroll
+            for (int q = 0; q < KW; ++q) dma_w(nxt, q, chn);
+        }
+#endif
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int s = (LC_ABLATE & 4) ? 0 : (tap & 1);
@@ -1086,7 +1098,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
             if (NTAP == 1) {
 #pragma unroll
                 for (int q = 0; q < KW; ++q) dma_w(nxt, q, chn);
-            } else if (tap < KW) {
+            } else if (tap < KW && !LC_DMA_FIRST) {
                 dma_w(nxt, tap, chn);
             }
             // loads of this chunk's successor were issued before tap 0; consume them as late as
@@ -1212,7 +1224,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_pipe_kernel(Con
         {
             int later = 0;
 #pragma unroll
-            for (int tap = (NTAP == 1 ? 1 : KW); tap < NTAP; ++tap) {
+            for (int tap = (NTAP == 1 ? 1 : (LC_DMA_FIRST ? 0 : KW)); tap < NTAP; ++tap) {
                 const int sl = dslot0 + tap;
                 if (dslot0 >= 0 && sl < DE::NUSED) later += DE::ops_of(sl);
             }

@@ -110,11 +110,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
     int x_loc[NXU];                                        // position r * XW + column of the pair's pixels, -1 = outside the image
     x_loc[0] = (x_has && x_p >= 1) ? x_r * XW + 2 * x_p - 1 : -1;
     x_loc[1] = (x_has && 2 * x_p < XW) ? x_r * XW + 2 * x_p : -1;
-    // The loads of a step are issued TWO stage slots (four phases) before the slot that stages it -- one slot ahead
-    // left every slot waiting ~1 us for them (profiles/r04_pp_kernel.txt) -- into one of two register sets; a set
-    // carries the byte offset its loads used (the sentinel marks a row outside the image: it stages exact zeros).
+    // The loads of a step are issued one stage slot (two phases) before the slot that stages it, into the registers
+    // that slot has just consumed; the set carries the byte offset its loads used (the sentinel marks a row outside
+    // the image: it stages exact zeros).  (A second set -- loads two slots ahead -- was tried: hipcc waits for it with
+    // vmcnt(0) across the loop back-edge, which defeats it; profiles/r04_pp_kernel.txt.)
     struct XSet { float v[NXU][8]; unsigned voff; };       // v[pixel of the pair][channel]
-    XSet xsa, xsb;
+    XSet xsa;
     auto x_offset = [&](int v) __attribute__((always_inline)) {   // byte offset of this thread's pair in channel grp * 8, strip of step v
         const int t = (v < NSTEP ? v : NSTEP - 1) / nchunk;
         const int gh = (th0 + t) * G::TH - 1 + x_r;
@@ -162,8 +163,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
     for (int i = tid; i < BN; i += G::NT)
         bias_s[i] = (a.bias && co0 + i < a.Co) ? a.bias[co0 + i] * (1.0f / out_unscale) : 0.0f;
     if (grp == 0) dma_w(0);
-    // set of step v = (v + grp) & 1: then both groups use set b, then set a, in each pair of loop iterations
-    if (grp == 0) load_x(xsa, 0); else load_x(xsb, 0);
+    load_x(xsa, 0);
     if constexpr (GNM != 0) {
         if (a.gs.partials) {
             for (int i = tid; i < a.Cgn; i += G::NT) ctab[i] = gn_row_from_stats(a.gs, xptr, b, i, a.Ci, HW);
@@ -283,11 +283,11 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
 #pragma unroll
     for (int k = 0; k < 4 * TPX; ++k) rq[k] = 0.f;
     auto epi_load = [&](float (&dst)[4 * TPX], int m, unsigned row, bool real) __attribute__((always_inline)) {
-        const unsigned vo = real ? pv_lane : OOB;
         // no residual operand: no loads, and dst keeps the zeros it was initialised with (NOT re-zeroed here: a VALU
         // write of registers that loads may still target makes hipcc drain the VMEM queue first -- a vmcnt(0) in the
         // middle of the compute phase)
         if ((LC_PP_ABL & 32) || !rb) return;
+        const unsigned vo = real ? pv_lane : OOB;
 #pragma unroll
         for (int k = 0; k < 4 * TPX; ++k)
             dst[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -419,8 +419,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
     // VMEM order of a wave over one [compute; stage slot] pair:
     //   compute   R  4 * TPX residual loads of the octet its slot finalises (when there is a residual operand)
     //             D  9 weight-DMA pieces of the next step (group 0)
-    //   slot      A  stage_unit: consumes the x loads issued two slots earlier (in flight for four phases)
-    //             B  8 x loads (64 bit) of the step the slot AFTER the next stages (into the set just consumed)
+    //   slot      A  stage_unit: consumes the x loads of the previous slot's B (in flight for two phases)
+    //             B  8 x loads (64 bit) of the step the NEXT slot stages
     //                (VALU: final values of this slot's octet)
     //             S  NST stores: the octet + its statistics entries
     // At the end of the slot, vmcnt <= 8 + NST means: R and D have landed (VMEM returns in order), only B and S may
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
             for (int i = 0; i < NXU; ++i) stage_unit(xs_, i, v);
         }
         __builtin_amdgcn_sched_barrier(0);
-        load_x(xs_, v + 2);                                 // the step this set is staged for next
+        load_x(xs_, v + 1);                                 // the step the next slot stages
         __builtin_amdgcn_sched_barrier(0);
         const bool real = epi_m < 4;
         const int m = epi_m & 3;
@@ -447,19 +447,11 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
         if (real) ++epi_m;
         wait_vmcnt(8 + NST);
     };
-    // phase -1: both halves of step 0's image, the x loads of steps 1 and 2
-    if (grp == 0) {
+    // phase -1: both halves of step 0's image, the x loads of step 1
 #pragma unroll
-        for (int i = 0; i < NXU; ++i) stage_unit(xsa, i, 0);
-        load_x(xsb, 1);
-        load_x(xsa, 2);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NXU; ++i) stage_unit(xsb, i, 0);
-        load_x(xsa, 1);
-        load_x(xsb, 2);
-    }
-    wait_vmcnt(16);               // group 0's weight DMA of step 0 (older than the x loads consumed above) has landed
+    for (int i = 0; i < NXU; ++i) stage_unit(xsa, i, 0);
+    load_x(xsa, 1);
+    wait_vmcnt(8);                // group 0's weight DMA of step 0 (older than the x loads consumed above) has landed
     if (grp == 1) {
         phase_barrier();
         stage_slot(xsa, 1, -1);
@@ -482,10 +474,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
             phase_barrier();
         }
     };
-    for (int s = 0; s < NSTEP; s += 2) {   // (NSTEP is even: the launcher takes Ci % 32 == 0 only)
-        iteration(xsb, s);
-        iteration(xsa, s + 1);
-    }
+    for (int s = 0; s < NSTEP; ++s) iteration(xsa, s);
     // The last strip drains in the open (group 0: its octet 0 went out in the last stage slot, under group 1's last
     // compute phase; group 1 parks here, its octet 0's residual values arrived during that compute phase).  All
     // residual loads first -- a load behind a store would wait for the store's acknowledgement -- then the stores.
