@@ -35,6 +35,16 @@
 // outputs are bit-identical to it (tests/test_hip_parity.py::test_conv_pp_matches_pipe).
 // Constraints (callers fall back to the pipelined kernel otherwise): 3x3, Ci % 16 == 0, 64 <= Ci <= 512,
 // Co % 64 == 0, H % 4 == 0, W % 64 == 0.
+#ifndef LC_PP_DEPTH
+#define LC_PP_DEPTH 1     // fragment prefetch distance of the compute phase, in taps
+#endif
+#ifndef LC_PP_PRIO
+#define LC_PP_PRIO 0      // 1: s_setprio 2 for the duration of a compute phase
+#endif
+#ifndef LC_PP_DMA0
+#define LC_PP_DMA0 9      // weight-DMA pieces (of 9 per wave) issued by group 0's compute phase; the rest by group 1's stage
+                          // slot of the same phase
+#endif
 #ifndef LC_PP_ABL
 #define LC_PP_ABL 0   // developer ablation (wrong results): 1 no output stores, 2 no x loads, 4 no weight DMA, 8 no MFMAs,
                       // 16 no staging arithmetic / ds_write, 32 no residual loads
@@ -361,10 +371,11 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
         const half8* cxl = cxh + XUP;
         const half8* cwh = wbuf + (step & 1) * G::WB;
         const half8* cwl = cwh + WU;
-        // fragments are pipelined one tap ahead (six MFMAs = 192 cycles of cover)
-        half8 ah[2], al[2], bh[2][TPX], bl[2][TPX];
+        // fragments are pipelined LC_PP_DEPTH taps ahead (one tap = six MFMAs = 192 cycles of cover)
+        constexpr int NF = LC_PP_DEPTH + 1;
+        half8 ah[NF], al[NF], bh[NF][TPX], bl[NF][TPX];
         auto fetch = [&](int tap) __attribute__((always_inline)) {
-            const int dy = tap / 3, dx = tap - dy * 3, s = tap & 1;
+            const int dy = tap / 3, dx = tap - dy * 3, s = tap % NF;
             ah[s] = cwh[tap * G::CB * BN + wbase];
             al[s] = cwl[tap * G::CB * BN + wbase];
 #pragma unroll
@@ -373,14 +384,16 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
                 bl[s][j] = cxl[xbase + 32 * j + dy * XW + dx];
             }
         };
-        fetch(0);
+        if (LC_PP_PRIO) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int d = 0; d < LC_PP_DEPTH; ++d) fetch(d);
 #pragma unroll
         for (int tap = 0; tap < G::NTAP; ++tap) {
-            const int s = tap & 1;
+            const int s = tap % NF;
             __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < G::NTAP) fetch(tap + 1);
+            if (tap + LC_PP_DEPTH < G::NTAP) fetch(tap + LC_PP_DEPTH);
             if (tap == 1) epi_load(rq, res_m, res_row, res_real);
-            if (dma_step >= 0) dma_w_piece(dma_step, tap);
+            if (dma_step >= 0 && tap < LC_PP_DMA0) dma_w_piece(dma_step, tap);
             __builtin_amdgcn_sched_barrier(0);
             if (LC_PP_ABL & 8) {
                 asm volatile("" ::"v"(ah[s]), "v"(al[s]), "v"(bh[s][0]), "v"(bl[s][0]), "v"(bh[s][1]), "v"(bl[s][1]));
@@ -394,6 +407,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (LC_PP_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- the phase loop.  Both groups run the same straight-line loop  [compute(s); barrier; stage slot; barrier];
@@ -443,9 +457,15 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
         for (int k = 0; k < 4 * TPX; ++k) asm volatile("" : "+v"(ov[k]));
         asm volatile("" : "+v"(ev[0]), "+v"(ev[1]));
         __builtin_amdgcn_sched_barrier(0);
+        if (LC_PP_DMA0 < G::NWD && grp == 1 && v < NSTEP) {      // group 1's share of the pieces of step v (= its own next step)
+#pragma unroll
+            for (int q = LC_PP_DMA0; q < G::NWD; ++q) dma_w_piece(v, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         epi_store(m, ov, ev, real);
         if (real) ++epi_m;
-        wait_vmcnt(8 + NST);
+        // group 0: its pieces (issued in the compute phase before this slot) are older than B and S
+        if (LC_PP_DMA0 == G::NWD || grp == 0) wait_vmcnt(8 + NST);
     };
     // phase -1: both halves of step 0's image, the x loads of step 1
 #pragma unroll
@@ -466,6 +486,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16x2_pp_kernel(ConvArgsH a) {
         compute(s, (grp == 0 && s + 1 < NSTEP) ? s + 1 : -1, parks ? 0 : (epi_m & 3), parks ? strip_row(s / nchunk) : p_row,
                 parks || epi_m < 4);
         LC_T(t_comp)
+        if (LC_PP_DMA0 < G::NWD && grp == 1) {                  // group 1's pieces of its last slot: S and this phase's R behind them
+            if (rb) wait_vmcnt(NST + 4 * TPX); else wait_vmcnt(NST);
+        }
         phase_barrier();
         LC_T(t_cwait)
         if (grp == 0 || s + 1 < NSTEP) {
