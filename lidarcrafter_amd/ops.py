@@ -1283,7 +1283,8 @@ def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down
         with torch.inference_mode(False):
             zbuf = torch.empty(H * W, device=dev, dtype=torch.int64)
         check(lib().lc_project_workspace_init(zbuf.data_ptr(), H * W, st), "lc_project_workspace_init")
-        _proj_ws[key] = zbuf
+        if not torch.cuda.is_current_stream_capturing():   # (memory allocated during a capture belongs to that graph's pool)
+            _proj_ws[key] = zbuf
     img = torch.empty((H, W, 6), device=dev, dtype=_F32)
     win = torch.empty((H, W), device=dev, dtype=torch.int32)
     cells = torch.empty((N, 2), device=dev, dtype=torch.int32) if return_cells else None

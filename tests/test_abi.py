@@ -36,6 +36,39 @@ def test_library_exports_every_symbol():
     assert handle.lc_groupnorm_partials_elems(2, 64, 32, 1024, 8) == 2 * 8 * 64 * 2
 
 
+def test_argument_checks_refuse_before_any_launch():
+    """Shapes a kernel does not take are refused by the host entry with LC_EUNSUP / LC_EINVAL before anything is
+    dereferenced or launched (callable without a GPU): the ping-pong tile configuration (33) outside its shapes, a sample
+    too large for the kernels' 32-bit byte offsets, attention heads wider than 64 channels."""
+    import ctypes
+
+    from lidarcrafter_amd import _lib
+
+    h = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    LC_EINVAL, LC_EUNSUP = -1, -2
+    src = open(os.path.join(ROOT, "include", "lidarcrafter_hip.h")).read()
+    m = dict(re.findall(r"#define\s+(LC_E[A-Z]+)\s+\(?(-?\d+)\)?", src))
+    if m:
+        LC_EINVAL, LC_EUNSUP = int(m.get("LC_EINVAL", LC_EINVAL)), int(m.get("LC_EUNSUP", LC_EUNSUP))
+
+    def conv(Ci, Co, H, W, cfg, B=1):
+        return h.lc_conv2d_ring_f16x2_fwd(p, Ci * H * W, p, p, None, None, 0, p, Co * H * W, B, Ci, Co, H, W, 3, 1.0, cfg,
+                                          None, 0, 0, None, None, 8, p, p, None)
+
+    assert conv(48, 64, 8, 64, 33) == LC_EUNSUP        # Ci % 16 == 0 but < 64
+    assert conv(64, 96, 8, 64, 33) == LC_EUNSUP        # Co % 64
+    assert conv(64, 64, 6, 64, 33) == LC_EUNSUP        # H % 4
+    assert conv(64, 64, 8, 96, 33) == LC_EUNSUP        # W % 64
+    assert conv(1024, 64, 8, 64, 33) == LC_EUNSUP      # Ci > 512
+    assert conv(64, 64, 4096, 4095, 0) == LC_EUNSUP    # H * W >= 2^24 / 32-bit offsets
+    assert conv(64, 4096, 1024, 1024, 0) == LC_EUNSUP  # Co * H * W * 4 >= 2^31
+    assert h.lc_attention_bwd(p, p, p, p, p, p, p, p, p, p, 1, 32, 32, 96, 32, 1.0, None) == LC_EUNSUP
+    assert h.lc_attention_bwd(p, p, p, p, p, p, p, p, p, p, 0, 32, 32, 32, 32, 1.0, None) == LC_EINVAL
+    assert h.lc_project_workspace_init(None, 16, None) == LC_EINVAL
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly on CPU tensors instead of silently computing."""
     import torch
