@@ -298,6 +298,13 @@ int lc_attention_train_fwd(const float* q, const float* k, const float* v, float
 int lc_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                      const float* lse, float* dsum_scratch, float* dq, float* dk, float* dv, int BH, int Lq, int Lk,
                      int dqk, int dv_ch, float scale, lc_stream_t s);
+/* The same backward pass with the f16x2-split arithmetic of lc_attention_f16x2_fwd (three v_mfma_f32_32x32x16_f16 per
+ * product, fp32 accumulation; the default of lidarcrafter_amd.autograd).  The gradient dO may have any magnitude: its
+ * maximum is measured next to D and the power of two that normalises it is carried exactly through dP, dS and the
+ * outputs.  dsum_scratch: float [BH * Lq + 1] (the extra word holds max |dO|). */
+int lc_attention_bwd_f16x2(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                           const float* lse, float* dsum_scratch, float* dq, float* dk, float* dv, int BH, int Lq,
+                           int Lk, int dqk, int dv_ch, float scale, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse-diffusion update, one fused elementwise pass:

@@ -87,6 +87,7 @@ SIGNATURES = {
                                      i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "lc_attention_train_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
     "lc_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "lc_attention_bwd_f16x2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "lc_gate_bias_act": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),

@@ -48,6 +48,7 @@ TRAIN_WGRAD_PRECISION = os.environ.get("LC_TRAIN_WGRAD_PRECISION", "f16x2")
 # materialised scores (the round-2/3 route; kept for A/B and for heads wider than 64 channels).
 TRAIN_ATTENTION = os.environ.get("LC_TRAIN_ATTENTION", "hip")
 TRAIN_ATTN_FWD_PRECISION = os.environ.get("LC_TRAIN_ATTN_FWD_PRECISION", "f16x2")
+TRAIN_ATTN_BWD_PRECISION = os.environ.get("LC_TRAIN_ATTN_BWD_PRECISION", "f16x2")   # "f32": exact-fp32 MFMA backward
 
 
 def training_active(module: torch.nn.Module, *tensors) -> bool:
@@ -174,12 +175,12 @@ class FlashAttention(torch.autograd.Function):
         B, h, dqk, Lq = q.shape
         Lk, dv = k.shape[-1], v.shape[2]
         dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        scratch = torch.empty((B * h, Lq), device=q.device, dtype=torch.float32)
+        scratch = torch.empty(B * h * Lq + 1, device=q.device, dtype=torch.float32)
+        fn = lib().lc_attention_bwd_f16x2 if TRAIN_ATTN_BWD_PRECISION == "f16x2" else lib().lc_attention_bwd
         with torch.cuda.device(q.device):
-            check(lib().lc_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
-                                         lse.data_ptr(), scratch.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                         dvv.data_ptr(), B * h, Lq, Lk, dqk, dv, ctx.scale,
-                                         torch.cuda.current_stream().cuda_stream), "lc_attention_bwd")
+            check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                     scratch.data_ptr(), dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), B * h, Lq, Lk, dqk, dv, ctx.scale,
+                     torch.cuda.current_stream().cuda_stream), "lc_attention_bwd")
         return dq, dk, dvv, None
 
 
