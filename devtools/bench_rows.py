@@ -413,7 +413,7 @@ def train_step_cond(dev, B):
             "algorithmic_tflops": round(flop / dt / 1e12, 1),
             "train_conv_precision": AGm.TRAIN_CONV_PRECISION, "train_wgrad_precision": AGm.TRAIN_WGRAD_PRECISION,
             "note": "denoiser + layout encoder, forward + backward + AdamW, dropout as configured; convolutions "
-                    "as in train_step_c2; attention core = autograd.FlashAttention (HIP flash forward + fp32-MFMA backward, LC_TRAIN_ATTENTION), small dense layers are torch ops on the device"}
+                    "as in train_step_c2; attention core = autograd.FlashAttention (HIP flash forward + f16x2-split flash backward; LC_TRAIN_ATTENTION, LC_TRAIN_ATTN_{FWD,BWD}_PRECISION), small dense layers are torch ops on the device"}
 
 
 def object_branch(dev, n_obj, steps):
