@@ -74,6 +74,14 @@ int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks);
  * derived on the device (no host synchronisation): an all-zero / non-finite tensor keeps 256. */
 int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
                               float* wmeta, lc_stream_t s);
+/* The packed weight of a layer's INPUT-GRADIENT conv (dX = the same ring conv of dY with the transposed, 180-degree
+ * rotated kernel) straight from the layer's forward weight w_fwd [Cf_o][Cf_i][ks][ks] -- the rotation and transposition
+ * happen in the pack kernel's addressing, no rotated copy exists.  Co / Ci are those of the dX conv (Co = Cf_i,
+ * Ci = Cf_o).  wmeta_fwd (may be NULL) = the wmeta lc_pack_conv_weight_f16x2 wrote for the SAME version of w_fwd: its
+ * max|w| is reused (one launch instead of memset + reduction + pack).  Training packs every weight twice per step
+ * (lidarcrafter_amd/autograd.py ConvRing.backward). */
+int lc_pack_conv_weight_f16x2_dx(const float* w_fwd, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
+                                 float* wmeta, const float* wmeta_fwd, lc_stream_t s);
 /* Range state of ONE conv layer's input (device memory, 16 bytes, owned by the caller, initialise
  * with {16, 1/16, 0, 0}).  The kernel multiplies x by x_scale before the fp16 hi/lo split and
  * publishes the largest |x * x_scale| it staged (after the fused input GroupNorm, if any) into
@@ -92,6 +100,12 @@ typedef struct lc_conv_range {
  * the backward: lidarcrafter_amd/autograd.py), where a poll-and-repeat protocol is not available. */
 int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t n, lc_conv_range* range,
                          lc_stream_t s);
+/* The same record from the partial maxima the PRODUCER of x left while writing it (amax: n device floats whose maximum is
+ * max|x| -- lc_groupnorm_apply_amax / lc_groupnorm_bwd_amax store one per block, no atomics) -- one single-block launch,
+ * x is not read again.  bound_mult >= 1 (LC_EINVAL otherwise): the tensor the conv will read is an elementwise rescale of
+ * the measured one by at most this factor (dropout: 1 / (1 - p)); max|x| * bound_mult is then an upper bound, which is
+ * all the record needs. */
+int lc_range_from_amax(const float* amax, int64_t n, float bound_mult, lc_conv_range* range, lc_stream_t s);
 /* Producer-side GroupNorm statistics of one channel segment: the entries a conv wrote through
  * gn_ostats_out (below), consumed by lc_groupnorm_apply_os or by the next conv's fused input norm. */
 typedef struct lc_oct_stats {
@@ -213,6 +227,13 @@ int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials, con
                        const float* beta, const float* scale, const float* shift, int64_t ss_bs,
                        float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
                        int act_silu, lc_stream_t s);
+/* ... and stores max|y| of every block of the pass into amax_out[0 .. lc_groupnorm_amax_partials(B, C, H, W, G, 0))
+ * (may be NULL; every element is written, nothing to initialise) for lc_range_from_amax of the conv that consumes y. */
+int64_t lc_groupnorm_amax_partials(int B, int C, int H, int W, int G, int backward);
+int lc_groupnorm_apply_amax(const float* x, int64_t x_bs, const double* partials, const float* gamma,
+                            const float* beta, const float* scale, const float* shift, int64_t ss_bs,
+                            float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
+                            int act_silu, float* amax_out, lc_stream_t s);
 
 /* The same normalisation from the PRODUCER's octet statistics (lc_conv2d_ring_f16x2_fwd
  * gn_ostats_out): one launch, the tensor is read once.  A tensor may be the channel concatenation of
@@ -380,6 +401,17 @@ int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
                      const float* mean_rstd, const float* gamma, const float* beta, const float* scale,
                      const float* shift, int64_t ss_bs, double* rows, float* dx, int64_t dx_bs, int B,
                      int C, int H, int W, int G, int act_silu, lc_stream_t s);
+/* The parameter gradients from `rows` in one launch (fp64 arithmetic, fp32 results; any output may be NULL):
+ * dgamma, dbeta [C]; dscale, dshift [B, C] contiguous.  gamma / beta / scale as passed to lc_groupnorm_bwd. */
+int lc_groupnorm_param_grads(const double* rows, const float* gamma, const float* beta, const float* scale,
+                             int64_t ss_bs, int B, int C, float* dgamma, float* dbeta, float* dscale,
+                             float* dshift, lc_stream_t s);
+/* ... and the partial maxima of |dx| into amax_out[0 .. lc_groupnorm_amax_partials(..., 1)) (as lc_groupnorm_apply_amax):
+ * dx is the dY of the conv that produced x. */
+int lc_groupnorm_bwd_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                          const float* mean_rstd, const float* gamma, const float* beta, const float* scale,
+                          const float* shift, int64_t ss_bs, double* rows, float* dx, int64_t dx_bs, int B,
+                          int C, int H, int W, int G, int act_silu, float* amax_out, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Voxel scatter of the weight-free metrics (lidargen/metrics/metric_utils.py).

@@ -9,17 +9,20 @@ training takes a second, plain composition of the same layers in which every hea
 
   ConvRing      forward  lc_conv2d_ring_*_fwd
                 backward dX: the same ring convolution of dY with the transposed, 180-degree rotated
-                         kernel (forward kernel);  dW, db: lc_conv2d_ring_wgrad[_f16x2] (MFMA implicit
+                         kernel (forward kernel; its weight packed straight from the forward weight,
+                         lc_pack_conv_weight_f16x2_dx);  dW, db: lc_conv2d_ring_wgrad[_f16x2] (MFMA implicit
                          GEMM over pixels, deterministic two-stage reduction)
-  GroupNormAct  forward  lc_groupnorm_stats + lc_groupnorm_apply (+ AdaGN scale/shift, + SiLU)
-                backward lc_groupnorm_bwd (rows + dx); parameter gradients contracted from the rows
+  GroupNormAct  forward  lc_groupnorm_stats + lc_groupnorm_apply_amax (+ AdaGN scale/shift, + SiLU; leaves the
+                         partial maxima of |y| for the range record of the conv that consumes y)
+                backward lc_groupnorm_bwd_amax (rows + dx, partial maxima of |dx|) + lc_groupnorm_param_grads
   Resample2x    forward  lc_resample2x_fwd;  backward: the adjoint FIR = the opposite resampling
                          (down^T = up / 4, up^T = 4 down: same window, ring / zero padding)
 
-The per-step glue that is tiny next to those -- time MLP and AdaGN projections ([B, 256] dense layers),
-the attention core of the two 512-token MHA blocks (1.8 % of the FLOPs), residual adds, channel
-concatenation -- runs as differentiable torch ops ON THE DEVICE in this round (their HIP backward
-kernels are the next step); nothing runs on the CPU.  Gradient parity against autograd of the CPU
+  FlashAttention forward lc_attention_train_fwd (flash kernel + log2-sum-exp); backward lc_attention_bwd[_f16x2]
+
+The per-step glue that is tiny next to those -- time MLP and AdaGN projections ([B, 256] dense layers), the
+13-token layout operands, residual adds, channel concatenation, dropout -- runs as differentiable torch ops ON
+THE DEVICE; nothing runs on the CPU.  Gradient parity against autograd of the CPU
 oracle: tests/test_training.py.  Data-parallel training: the parameters are ordinary
 nn.Parameters, so torch DistributedDataParallel (RCCL bucketed all-reduce overlapped with backward)
 wraps `ddpm` unchanged, exactly like `accelerator.prepare` does in the reference.
@@ -62,6 +65,60 @@ def training_active(module: torch.nn.Module, *tensors) -> bool:
     return active
 
 
+# max|.| left behind by the pass that WROTE a tensor (GroupNormAct forward / backward: one partial maximum per block, plain
+# stores), so that the conv consuming the tensor sets its range record from a few hundred floats instead of reading the
+# tensor again (lc_range_from_amax).  The tensor object carries (partials, version, data_ptr, bound_mult) and a consumer
+# trusts the tag only while version and address still match -- the autograd engine may accumulate a second gradient into
+# the same tensor in place, which bumps the version.
+PRODUCER_AMAX = os.environ.get("LC_TRAIN_PRODUCER_AMAX", "1") != "0"
+
+
+def _amax_slot(device, B, C, H, W, G, backward: bool) -> torch.Tensor:
+    n = int(lib().lc_groupnorm_amax_partials(B, C, H, W, G, int(backward)))
+    return torch.empty(n, device=device, dtype=torch.float32)
+
+
+def _tag_amax(t: torch.Tensor, slot: torch.Tensor, mult: float = 1.0) -> None:
+    t._lc_amax = (slot, t._version, t.data_ptr(), mult)
+
+
+def _amax_of(t: torch.Tensor):
+    """(partials, bound_mult) if `t` still is the tensor its producer measured, else None."""
+    tag = getattr(t, "_lc_amax", None)
+    if tag is None or tag[1] != t._version or tag[2] != t.data_ptr():
+        return None
+    return tag[0], tag[3]
+
+
+def _carry_amax(src: torch.Tensor, dst: torch.Tensor, mult: float = 1.0) -> torch.Tensor:
+    """`dst` holds the values of `src` (a view / reshape) or an elementwise contraction of them by at most `mult`."""
+    m = _amax_of(src) if PRODUCER_AMAX else None
+    if m is not None:
+        _tag_amax(dst, m[0], m[1] * mult)
+    return dst
+
+
+def _tag_amax(t: torch.Tensor, slot: torch.Tensor, mult: float = 1.0) -> None:
+    t._lc_amax = (slot, t._version, t.data_ptr(), mult)
+
+
+def _amax_of(t: torch.Tensor):
+    """(slot, bound_mult) if `t` still is the tensor its producer measured, else None."""
+    tag = getattr(t, "_lc_amax", None)
+    if tag is None or tag[1] != t._version or tag[2] != t.data_ptr():
+        return None
+    return tag[0], tag[3]
+
+
+def dropout(h: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """F.dropout that keeps the producer's max|h| usable: the kept elements are h / (1 - p), so max|h| / (1 - p) bounds
+    the result (an upper bound is all a range record needs)."""
+    if not training or p <= 0.0:
+        return h
+    y = F.dropout(h, p, training=True)
+    return _carry_amax(h, y, 1.0 / (1.0 - p)) if p < 1.0 else y
+
+
 def _c4(t):
     """A [B,C,H,W] tensor the kernels can take as it is: inner [C,H,W] block contiguous, ANY batch
     stride (the gradient of a channel concatenation arrives as a slice of the concatenated
@@ -84,11 +141,14 @@ class ConvRing(torch.autograd.Function):
     """y = conv_ring(x, W) + b (3x3: W circular / H zero padding, 1x1: plain)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, holder):
+    def forward(ctx, x, weight, bias, holder, amax=None):
         x = _c4(x)
         x_rec = None
         if TRAIN_CONV_PRECISION == "f16x2":
-            K.range_from_tensor(x, holder["fwd"])
+            if amax is not None:
+                K.range_from_amax(amax[0], holder["fwd"], x.device, amax[1])
+            else:
+                K.range_from_tensor(x, holder["fwd"])
             # the record x was measured with, kept with the saved activation: the same module may run forward again
             # (shared weights, two forwards feeding one loss) before this backward and re-measure the live record
             x_rec = holder["fwd"].range_snapshot(x.device)
@@ -100,6 +160,7 @@ class ConvRing(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        dy_amax = _amax_of(dy) if PRODUCER_AMAX else None      # of the tensor as its producer handed it over
         dy = _c4(dy)
         B, Ci, H, W = x.shape
         Co, ks = weight.shape[0], weight.shape[-1]
@@ -110,10 +171,18 @@ class ConvRing(torch.autograd.Function):
                    H % 2 == 0 and W % 32 == 0 and _bs(x) % 4 == 0 and _bs(dy) % 4 == 0 and
                    x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
         if TRAIN_CONV_PRECISION == "f16x2" and (ctx.needs_input_grad[0] or w_split):
-            K.range_from_tensor(dy, ctx.holder["bwd"])         # one measurement serves dX and dW
+            if dy_amax is not None:                             # one measurement serves dX and dW
+                K.range_from_amax(dy_amax[0], ctx.holder["bwd"], dy.device, dy_amax[1])
+            else:
+                K.range_from_tensor(dy, ctx.holder["bwd"])
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [Ci, Co, ks, ks]
-            dx = K.conv2d_ring(dy, ctx.holder["bwd"], wt, None, precision=TRAIN_CONV_PRECISION)
+            if TRAIN_CONV_PRECISION == "f16x2":
+                # the transposed, rotated kernel is packed straight from the forward weight
+                dx = K.conv2d_ring(dy, ctx.holder["bwd"], weight.detach(), None, precision="f16x2",
+                                   weight_is_fwd=True, dx_of=ctx.holder["fwd"])
+            else:
+                wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()       # [Ci, Co, ks, ks]
+                dx = K.conv2d_ring(dy, ctx.holder["bwd"], wt, None, precision=TRAIN_CONV_PRECISION)
         if need_w:
             dw = torch.empty_like(weight)
             db = torch.empty(Co, device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -133,7 +202,7 @@ class ConvRing(torch.autograd.Function):
                                                      scratch.data_ptr(), dw.data_ptr(),
                                                      None if db is None else db.data_ptr(), B, Ci, Co, H,
                                                      W, ks, 0, st), "lc_conv2d_ring_wgrad")
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def conv(module, x):
@@ -143,7 +212,7 @@ def conv(module, x):
         holder = {"fwd": K.PackedConv("train.fwd"), "bwd": K.PackedConv("train.bwd")}
         module.__dict__["_train_packed"] = holder
     w = module.weight if module.weight.dim() == 4 else module.weight[:, :, :, None]
-    return ConvRing.apply(x, w, module.bias, holder)
+    return ConvRing.apply(x, w, module.bias, holder, _amax_of(x) if PRODUCER_AMAX else None)
 
 
 class FlashAttention(torch.autograd.Function):
@@ -213,11 +282,13 @@ class GroupNormAct(torch.autograd.Function):
                   "lc_groupnorm_stats")
             check(lib().lc_groupnorm_meanrstd(x.data_ptr(), _bs(x), part.data_ptr(), mr.data_ptr(), B,
                                               C, H, W, G, float(eps), st), "lc_groupnorm_meanrstd")
-            check(lib().lc_groupnorm_apply(x.data_ptr(), _bs(x), part.data_ptr(), p(gamma), p(beta),
-                                           p(sc), p(sf), C, y.data_ptr(), C * H * W, B, C, H, W, G,
-                                           float(eps), int(act), st), "lc_groupnorm_apply")
+            slot = _amax_slot(dev, B, C, H, W, G, False) if PRODUCER_AMAX and TRAIN_CONV_PRECISION == "f16x2" else None
+            check(lib().lc_groupnorm_apply_amax(x.data_ptr(), _bs(x), part.data_ptr(), p(gamma), p(beta),
+                                                p(sc), p(sf), C, y.data_ptr(), C * H * W, B, C, H, W, G,
+                                                float(eps), int(act), p(slot), st), "lc_groupnorm_apply_amax")
         ctx.save_for_backward(x, mr, gamma, beta, sc, sf)
         ctx.G, ctx.act = G, act
+        ctx.amax_slot = slot             # the tag itself is set on the tensor apply() returns (group_norm below)
         return y
 
     @staticmethod
@@ -229,28 +300,44 @@ class GroupNormAct(torch.autograd.Function):
         dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         p = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(x.device):
-            check(lib().lc_groupnorm_bwd(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), mr.data_ptr(),
-                                         p(gamma), p(beta), p(sc), p(sf), C, rows.data_ptr(),
-                                         dx.data_ptr(), C * H * W, B, C, H, W, ctx.G, int(ctx.act),
-                                         torch.cuda.current_stream().cuda_stream), "lc_groupnorm_bwd")
-        r1, r3 = rows[..., 0], rows[..., 1]                       # [B, C] fp64
-        one_sc = 1.0 if sc is None else (1.0 + sc.double())
-        g = 1.0 if gamma is None else gamma.double()[None]
-        be = 0.0 if beta is None else beta.double()[None]
-        dgamma = dbeta = dscale = dshift = None
-        if gamma is not None:
-            dgamma = (one_sc * r3).sum(0).float()
-            dbeta = (one_sc * r1).sum(0).float()
-        if sc is not None:
-            dscale = (g * r3 + be * r1).float()
-            dshift = r1.float()
+            slot = _amax_slot(x.device, B, C, H, W, ctx.G, True) \
+                if PRODUCER_AMAX and TRAIN_CONV_PRECISION == "f16x2" else None
+            check(lib().lc_groupnorm_bwd_amax(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), mr.data_ptr(),
+                                              p(gamma), p(beta), p(sc), p(sf), C, rows.data_ptr(),
+                                              dx.data_ptr(), C * H * W, B, C, H, W, ctx.G, int(ctx.act), p(slot),
+                                              torch.cuda.current_stream().cuda_stream), "lc_groupnorm_bwd_amax")
+            if slot is not None:
+                _tag_amax(dx, slot)      # dx is the dY of the conv that produced x (when nothing else consumed x)
+            # the small parameter gradients from the rows: one launch (dshift = r1, dscale = g r3 + be r1,
+            # dbeta = sum_b (1 + sc) r1, dgamma = sum_b (1 + sc) r3; fp64 arithmetic)
+            dgamma = dbeta = dscale = dshift = None
+            if gamma is not None:
+                dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+                dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+            if sc is not None:
+                dscale = torch.empty((B, C), device=x.device, dtype=torch.float32)
+                dshift = torch.empty((B, C), device=x.device, dtype=torch.float32)
+            if gamma is not None or sc is not None:
+                check(lib().lc_groupnorm_param_grads(rows.data_ptr(), p(gamma), p(beta), p(sc), C, B, C, p(dgamma),
+                                                     p(dbeta), p(dscale), p(dshift),
+                                                     torch.cuda.current_stream().cuda_stream),
+                      "lc_groupnorm_param_grads")
+            if beta is None:
+                dbeta = None
+            if sf is None:
+                dshift = None
         return dx, dgamma, dbeta, dscale, dshift, None, None, None
 
 
 def group_norm(module, x, act=False, scale=None, shift=None):
     gamma = getattr(module, "weight", None)
     beta = getattr(module, "bias", None)
-    return GroupNormAct.apply(x, gamma, beta, scale, shift, module.num_groups, module.eps, act)
+    y = GroupNormAct.apply(x, gamma, beta, scale, shift, module.num_groups, module.eps, act)
+    fn = y.grad_fn
+    slot = getattr(fn, "amax_slot", None) if fn is not None else None
+    if slot is not None:
+        _tag_amax(y, slot)
+    return y
 
 
 class Resample2x(torch.autograd.Function):
@@ -268,7 +355,9 @@ class Resample2x(torch.autograd.Function):
 
 
 def resample(x, up: bool):
-    return Resample2x.apply(x, up)
+    # |resampled| <= max|x|: every output sample is a convex combination of inputs (down: [1,3,3,1]/8 per axis; up:
+    # gain 2 on the zero-stuffed signal = the phases [1,3]/4 and [3,1]/4 per axis)
+    return _carry_amax(x, Resample2x.apply(x, up))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -346,18 +435,21 @@ class _LinearAsConv:
 # ------------------------------------------------------------------------------------------------
 def _tok(x3):
     """[B, C, L] tokens as the [B, C, 1, L] image the conv / GroupNorm Functions take."""
-    return x3.unsqueeze(2)
+    return _carry_amax(x3, x3.unsqueeze(2))
 
 
 def _gn_tok(module, x3, **kw):
-    return group_norm(module, _tok(x3), **kw).squeeze(2)
+    y = group_norm(module, _tok(x3), **kw)
+    return _carry_amax(y, y.squeeze(2))
 
 
 def _conv_tok(module, x3):
-    """1x1 projection of channel-major tokens: the MFMA conv for image-sized token sets, a torch
-    conv1d for the 13-token layout operands (a few kFLOP)."""
+    """1x1 projection of channel-major tokens: the MFMA conv for image-sized token sets, one dense
+    product for the 13-token layout operands (a few kFLOP; NOT F.conv1d -- MIOpen answers that shape with
+    a Winograd forward and a naive backward kernel of 0.36 ms per call, 6 ms of a C3 training step)."""
     if x3.shape[-1] < 64:
-        return F.conv1d(x3, module.weight, module.bias)
+        y = torch.matmul(module.weight[:, :, 0], x3)
+        return y if module.bias is None else y + module.bias[:, None]
     return conv(module, _tok(x3)).squeeze(2)
 
 
@@ -396,7 +488,7 @@ def layout_unet_v1_forward(m, x: torch.Tensor, cond_dict: dict) -> torch.Tensor:
         e = F.linear(F.silu(emb), rb.emb_layers[1].weight, rb.emb_layers[1].bias)
         C = rb.out_channels
         h = group_norm(rb.out_layers[0], h, act=True, scale=e[:, :C], shift=e[:, C:])
-        h = F.dropout(h, rb.dropout, training=rb.training)
+        h = dropout(h, rb.dropout, rb.training)
         h = conv(rb.out_layers[3], h)
         sk = x if isinstance(rb.skip_connection, torch.nn.Identity) else conv(rb.skip_connection, x)
         return sk + h

@@ -29,3 +29,38 @@ __device__ __forceinline__ float lc_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// max |.| of a block -> *slot (a float seen as its bit pattern; non-negative floats order like unsigned).  One atomicMax
+// per BLOCK, and only when the block's maximum beats what is already published (thousands of same-address atomics
+// serialise in L2: 150 us per call in the first version).  NaN / 0 never win.  Every thread of the block must call it.
+__device__ __forceinline__ void lc_block_amax_publish(float am, unsigned* slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    __shared__ float wmax[16];
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wmax[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, wmax[i]);
+        const unsigned bits = __float_as_uint(m);
+        if (m > 0.0f && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(slot, bits);
+    }
+}
+
+// max |.| of a block -> *out as a plain store (no atomics, nothing to wait for: a pass with thousands of short blocks
+// leaves one partial maximum per block and the consumer reduces them).  Every thread of the block must call it.
+__device__ __forceinline__ void lc_block_amax_store(float am, float* out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    __shared__ float wmax_s[16];
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) wmax_s[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wmax_s[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, wmax_s[i]);
+        *out = m;
+    }
+}

@@ -1808,31 +1808,13 @@ int auto_cfg_h(int B, int Ci, int Co, int H, int W, int ks) {
     return 3;
 }
 
-// One atomicMax per BLOCK, and only when the block's maximum beats what is already published
-// (thousands of same-address atomics serialise in L2: 150 us per call in the first version).
-__device__ __forceinline__ void block_amax_publish(float am, unsigned* slot) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-    __shared__ float wmax[16];
-    const int nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = wmax[0];
-        for (int i = 1; i < nw; ++i) m = fmaxf(m, wmax[i]);
-        const unsigned bits = __float_as_uint(m);
-        if (m > 0.0f && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(slot, bits);
-    }
-}
-
 // max |w| of the tensor -> wmeta[2] (atomicMax on the bit pattern; wmeta zeroed before)
 __global__ void weight_amax_kernel(const float* __restrict__ w, long long n, float* wmeta) {
     float am = 0.0f;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x)
         am = fmaxf(am, fabsf(w[e]));
-    block_amax_publish(am, reinterpret_cast<unsigned*>(wmeta + 2));
+    lc_block_amax_publish(am, reinterpret_cast<unsigned*>(wmeta + 2));
 }
 
 // the weight pre-scale from max|w| (see lc_pack_conv_weight_f16x2 in the header)
@@ -1847,11 +1829,20 @@ __device__ __forceinline__ float weight_scale_for(float amax) {
     return ldexpf(1.0f, k);                             // amax * scale in [2^12, 2^13)
 }
 
+// DX = false: w is the conv's own OIHW weight [Co][Ci][ntap].  DX = true: w is the FORWARD weight [Ci][Co][ntap] of the
+// layer whose input gradient this conv computes -- the packed weight is its transpose with both kernel axes flipped
+// (wt[co][ci][tap] = w[ci][co][ntap-1-tap]), read in place: no flipped / transposed copy exists; amax_src (may be
+// NULL) = the wmeta of the forward pack of the same weight version, whose max|w| is this one's too.
+template <bool DX>
 __global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __restrict__ ph,
                                      _Float16* __restrict__ pl, int Co, int Ci, int ntap, int Cib,
-                                     int Cop, float* wmeta) {
-    const float ws = weight_scale_for(wmeta[2]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { wmeta[0] = ws; wmeta[1] = 1.0f / ws; }
+                                     int Cop, float* wmeta, const float* __restrict__ amax_src) {
+    const float amax = amax_src ? amax_src[2] : wmeta[2];
+    const float ws = weight_scale_for(amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wmeta[0] = ws; wmeta[1] = 1.0f / ws;
+        if (amax_src) { wmeta[2] = amax; wmeta[3] = 0.0f; }
+    }
     const long long n = (long long)ntap * Cib * Cop * 8;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x) {
@@ -1861,7 +1852,10 @@ __global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __re
         const int cb = r % Cib;
         const int tap = r / Cib;
         const int ci = cb * 8 + k;
-        const float v = (co < Co && ci < Ci) ? w[((long long)co * Ci + ci) * ntap + tap] * ws : 0.0f;
+        float v = 0.0f;
+        if (co < Co && ci < Ci)
+            v = (DX ? w[((long long)ci * Co + co) * ntap + (ntap - 1 - tap)]
+                    : w[((long long)co * Ci + ci) * ntap + tap]) * ws;
         // the split rule of the activations: hi = 11 significant bits (truncated, exact), lo = rest
         const float hf = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
         ph[e] = (_Float16)hf;
@@ -1876,19 +1870,39 @@ extern "C" int64_t lc_packed_conv_weight_f16x2_elems(int Co, int Ci, int ks) {
     return (int64_t)ks * ks * Cip * Cop;  // halves per plane (hi and lo planes each this size)
 }
 
-extern "C" int lc_pack_conv_weight_f16x2(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci,
-                                         int ks, float* wmeta, lc_stream_t s) {
+namespace {
+int pack_weight_h(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci, int ks, float* wmeta,
+                  const float* amax_src, bool dx, lc_stream_t s) {
     if (!w || !wp_hi || !wp_lo || !wmeta || Co <= 0 || Ci <= 0 || (ks != 1 && ks != 3)) return LC_EINVAL;
     const int Cib = (Ci + 15) / 16 * 2, Cop = (Co + 63) / 64 * 64;
     const long long n = (long long)ks * ks * Cib * Cop * 8;
     const long long nw = (long long)Co * Ci * ks * ks;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     const int ablocks = (int)((nw + 255) / 256 > 1024 ? 1024 : (nw + 255) / 256);
-    if (hipMemsetAsync(wmeta, 0, 4 * sizeof(float), lc_s(s)) != hipSuccess) return lc_launch_status();
-    hipLaunchKernelGGL(weight_amax_kernel, dim3(ablocks), dim3(256), 0, lc_s(s), w, nw, wmeta);
-    hipLaunchKernelGGL(pack_weight_h_kernel, dim3(blocks), dim3(256), 0, lc_s(s), w,
-                       (_Float16*)wp_hi, (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop, wmeta);
+    if (!amax_src) {
+        if (hipMemsetAsync(wmeta, 0, 4 * sizeof(float), lc_s(s)) != hipSuccess) return lc_launch_status();
+        hipLaunchKernelGGL(weight_amax_kernel, dim3(ablocks), dim3(256), 0, lc_s(s), w, nw, wmeta);
+    }
+    if (dx)
+        hipLaunchKernelGGL(pack_weight_h_kernel<true>, dim3(blocks), dim3(256), 0, lc_s(s), w, (_Float16*)wp_hi,
+                           (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop, wmeta, amax_src);
+    else
+        hipLaunchKernelGGL(pack_weight_h_kernel<false>, dim3(blocks), dim3(256), 0, lc_s(s), w, (_Float16*)wp_hi,
+                           (_Float16*)wp_lo, Co, Ci, ks * ks, Cib, Cop, wmeta, amax_src);
     return lc_launch_status();
+}
+}  // namespace
+
+extern "C" int lc_pack_conv_weight_f16x2(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci,
+                                         int ks, float* wmeta, lc_stream_t s) {
+    return pack_weight_h(w, wp_hi, wp_lo, Co, Ci, ks, wmeta, nullptr, false, s);
+}
+
+// Packed weight of the INPUT-GRADIENT conv of a layer, straight from the layer's forward weight w_fwd [Cf_o][Cf_i][ks][ks]:
+// the dX conv has Co = Cf_i output and Ci = Cf_o input channels (pass THOSE as Co / Ci).
+extern "C" int lc_pack_conv_weight_f16x2_dx(const float* w_fwd, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
+                                            float* wmeta, const float* wmeta_fwd, lc_stream_t s) {
+    return pack_weight_h(w_fwd, wp_hi, wp_lo, Co, Ci, ks, wmeta, wmeta_fwd, true, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1918,10 +1932,9 @@ __global__ void tensor_amax_kernel(const float* __restrict__ x, long long x_bs, 
                 am = fmaxf(am, fabsf(p[e]));
         }
     }
-    block_amax_publish(am, reinterpret_cast<unsigned*>(&rg->reserved));   // NaN / 0 never win; inf is handled below
+    lc_block_amax_publish(am, reinterpret_cast<unsigned*>(&rg->reserved));   // NaN / 0 never win; inf is handled below
 }
-__global__ void range_set_kernel(lc_conv_range* rg) {
-    const float amax = rg->reserved;
+__device__ __forceinline__ void range_record_set(lc_conv_range* rg, float amax) {
     float sc = X_PRESCALE_DEFAULT;
     if (amax > 0.0f && amax < 3.0e38f) {
         int e;
@@ -1935,6 +1948,17 @@ __global__ void range_set_kernel(lc_conv_range* rg) {
     rg->amax_scaled = 0.0f;
     rg->reserved = 0.0f;
 }
+__global__ void range_set_kernel(lc_conv_range* rg) { range_record_set(rg, rg->reserved); }
+__global__ void range_from_amax_kernel(lc_conv_range* rg, const float* __restrict__ amax, long long n, float bound_mult) {
+    float m = 0.0f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, amax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) range_record_set(rg, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])) * bound_mult);
+}
 
 extern "C" int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t n, lc_conv_range* range,
                                     lc_stream_t s) {
@@ -1945,6 +1969,15 @@ extern "C" int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t
     hipLaunchKernelGGL(tensor_amax_kernel, dim3((unsigned)bx, by), dim3(256), 0, lc_s(s), x, (long long)x_bs,
                        (long long)n, B, range);
     hipLaunchKernelGGL(range_set_kernel, dim3(1), dim3(1), 0, lc_s(s), range);
+    return lc_launch_status();
+}
+
+// The record from the partial maxima some PRODUCER of x left while writing it (lc_groupnorm_apply_amax /
+// lc_groupnorm_bwd_amax: one float per block of the pass) -- the extra read of x by lc_range_from_tensor disappears.
+// bound_mult >= 1: x is a known elementwise contraction / rescale of the measured tensor (dropout: 1 / (1 - p)).
+extern "C" int lc_range_from_amax(const float* amax, int64_t n, float bound_mult, lc_conv_range* range, lc_stream_t s) {
+    if (!amax || n <= 0 || !range || !(bound_mult >= 1.0f)) return LC_EINVAL;
+    hipLaunchKernelGGL(range_from_amax_kernel, dim3(1), dim3(256), 0, lc_s(s), range, amax, (long long)n, bound_mult);
     return lc_launch_status();
 }
 

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     const float* __restrict__ x, long long x_bs, const double* __restrict__ part,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
     const float* __restrict__ shift, long long ss_bs, float* __restrict__ y, long long y_bs, int C,
-    int G, long long HW, int nch, float eps, int act, int cpb) {
+    int G, long long HW, int nch, float eps, int act, int cpb, float* amax_out) {
     const int c_first = blockIdx.y * cpb, b = blockIdx.z;     // cpb channels of ONE group per block
+    float am = 0.0f;                                          // max |y| of this thread (amax_out != NULL)
     const int cpg = C / G, g = c_first / cpg;
     const double* pp = part + ((long long)b * G + g) * nch * 2;
     double s = 0.0, q = 0.0;
@@ -94,11 +95,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
                 f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
                 v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
                 *reinterpret_cast<f32x4*>(yp + i) = v;
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
         } else {
-            for (long long i = lo + threadIdx.x; i < hi; i += 256) yp[i] = f(xp[i]);
+            for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+                const float r = f(xp[i]);
+                yp[i] = r;
+                am = fmaxf(am, fabsf(r));
+            }
         }
     }
+    if (amax_out)
+        lc_block_amax_store(am, amax_out + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // Per-(b, channel) affine form of GroupNorm(+AdaGN): y = (x - mu) * A + Bc, stored as float4
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ scale, const float* __restrict__ shift, long long ss_bs,
     const double* __restrict__ rows, float* __restrict__ dx, long long dx_bs, int C, int G,
-    long long HW, int act) {
+    long long HW, int act, float* amax_out) {
     const int c = blockIdx.y, b = blockIdx.z, cpg = C / G, g = c / cpg;
     const float mu = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
     double m1 = 0.0, m2 = 0.0;                                  // group means of dxh and dxh * xh
@@ -323,12 +331,27 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     float* op = dx + b * dx_bs + (long long)c * HW;
     const long long per = (HW + gridDim.x - 1) / gridDim.x;
     const long long lo = blockIdx.x * per, hi = lo + per < HW ? lo + per : HW;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const float xh = (xp[i] - mu) * rstd;
-        float d = dp[i];
+    float am = 0.0f;
+    const auto g1 = [&](float xv, float d) {
+        const float xh = (xv - mu) * rstd;
         if (act) d *= silu_grad((xh * ga + be) * sc + sf);
-        op[i] = rstd * (ga * sc * d - fm1 - xh * fm2);
+        const float r = rstd * (ga * sc * d - fm1 - xh * fm2);
+        am = fmaxf(am, fabsf(r));
+        return r;
+    };
+    if ((HW & 3) == 0 && (per & 3) == 0 && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(dp) |
+                                             reinterpret_cast<uintptr_t>(op)) & 15) == 0) {
+        for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + i), dv = *reinterpret_cast<const f32x4*>(dp + i);
+            f32x4 r;
+            r.x = g1(xv.x, dv.x); r.y = g1(xv.y, dv.y); r.z = g1(xv.z, dv.z); r.w = g1(xv.w, dv.w);
+            *reinterpret_cast<f32x4*>(op + i) = r;
+        }
+    } else {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) op[i] = g1(xp[i], dp[i]);
     }
+    if (amax_out)
+        lc_block_amax_store(am, amax_out + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 template <bool OS>
@@ -500,27 +523,51 @@ extern "C" int lc_groupnorm_stats(const float* x, int64_t x_bs, double* partials
     return lc_launch_status();
 }
 
+namespace {
+// launch shape of gn_apply_kernel: slabs of >= 4096 elements; small planes: several channels of a group per block, so the
+// per-block fold of the partials (fp64 divide + sqrt) is paid once per >= 4096 elements while >= 512 blocks remain
+inline void gn_apply_grid(int B, int C, int G, long long HW, int* slabs, int* cpb) {
+    int sl = (int)((HW + 4095) / 4096);
+    if (sl < 1) sl = 1;
+    int c = 1;
+    const int cpg = C / G;
+    while (c * 2 <= cpg && cpg % (c * 2) == 0 && HW * c * 2 <= 4096 && (long long)B * (C / (c * 2)) * sl >= 512) c *= 2;
+    *slabs = sl; *cpb = c;
+}
+}  // namespace
+
+// floats lc_groupnorm_apply_amax (backward == 0) / lc_groupnorm_bwd_amax (backward != 0) write through amax_out: one
+// partial maximum per block of their apply pass
+extern "C" int64_t lc_groupnorm_amax_partials(int B, int C, int H, int W, int G, int backward) {
+    if (B <= 0 || C <= 0 || G <= 0 || C % G || H <= 0 || W <= 0) return 0;
+    int slabs, cpb;
+    gn_apply_grid(B, C, G, (long long)H * W, &slabs, &cpb);
+    return (int64_t)slabs * (backward ? C : C / cpb) * B;
+}
+
+extern "C" int lc_groupnorm_apply_amax(const float* x, int64_t x_bs, const double* partials,
+                                       const float* gamma, const float* beta, const float* scale,
+                                       const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B,
+                                       int C, int H, int W, int G, float eps, int act_silu,
+                                       float* amax_out, lc_stream_t s) {
+    if (!x || !y || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
+    const long long HW = (long long)H * W;
+    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
+    int slabs, cpb;
+    gn_apply_grid(B, C, G, HW, &slabs, &cpb);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
+                       (long long)x_bs, partials, gamma, beta, scale, shift, (long long)ss_bs, y,
+                       (long long)y_bs, C, G, HW, nch, eps, act_silu, cpb, amax_out);
+    return lc_launch_status();
+}
+
 extern "C" int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials,
                                   const float* gamma, const float* beta, const float* scale,
                                   const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B,
                                   int C, int H, int W, int G, float eps, int act_silu,
                                   lc_stream_t s) {
-    if (!x || !y || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
-    const long long HW = (long long)H * W;
-    const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
-    int slabs = (int)((HW + 4095) / 4096);  // >= 4096 elements per block
-    if (slabs < 1) slabs = 1;
-    // small planes: several channels of a group per block, so the per-block fold of the partials
-    // (fp64 divide + sqrt) is paid once per >= 4096 elements while >= 512 blocks remain
-    int cpb = 1;
-    const int cpg = C / G;
-    while (cpb * 2 <= cpg && cpg % (cpb * 2) == 0 && HW * cpb * 2 <= 4096 &&
-           (long long)B * (C / (cpb * 2)) * slabs >= 512)
-        cpb *= 2;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
-                       (long long)x_bs, partials, gamma, beta, scale, shift, (long long)ss_bs, y,
-                       (long long)y_bs, C, G, HW, nch, eps, act_silu, cpb);
-    return lc_launch_status();
+    return lc_groupnorm_apply_amax(x, x_bs, partials, gamma, beta, scale, shift, ss_bs, y, y_bs, B, C, H, W, G, eps,
+                                   act_silu, nullptr, s);
 }
 
 
@@ -631,11 +678,44 @@ extern "C" int lc_groupnorm_meanrstd(const float* x, int64_t x_bs, const double*
     return lc_launch_status();
 }
 
-extern "C" int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
-                                const float* mean_rstd, const float* gamma, const float* beta,
-                                const float* scale, const float* shift, int64_t ss_bs, double* rows,
-                                float* dx, int64_t dx_bs, int B, int C, int H, int W, int G,
-                                int act_silu, lc_stream_t s) {
+// The small parameter gradients of GroupNorm(+AdaGN) from the rows of lc_groupnorm_bwd, one thread per channel, fp64,
+// samples in ascending order (deterministic):  dshift[b,c] = r1,  dscale[b,c] = g r3 + be r1,
+// dbeta[c] = sum_b (1 + sc) r1,  dgamma[c] = sum_b (1 + sc) r3.
+__global__ void gn_param_grads_kernel(const double* __restrict__ rows, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ scale,
+                                      long long ss_bs, int B, int C, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, float* __restrict__ dscale,
+                                      float* __restrict__ dshift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+    double ag = 0.0, ab = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double r1 = rows[2 * ((long long)b * C + c)], r3 = rows[2 * ((long long)b * C + c) + 1];
+        const double one_sc = scale ? 1.0 + (double)scale[b * ss_bs + c] : 1.0;
+        ag += one_sc * r3;
+        ab += one_sc * r1;
+        if (dscale) dscale[(long long)b * C + c] = (float)(g * r3 + be * r1);
+        if (dshift) dshift[(long long)b * C + c] = (float)r1;
+    }
+    if (dgamma) dgamma[c] = (float)ag;
+    if (dbeta) dbeta[c] = (float)ab;
+}
+
+extern "C" int lc_groupnorm_param_grads(const double* rows, const float* gamma, const float* beta,
+                                        const float* scale, int64_t ss_bs, int B, int C, float* dgamma,
+                                        float* dbeta, float* dscale, float* dshift, lc_stream_t s) {
+    if (!rows || B <= 0 || C <= 0) return LC_EINVAL;
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, lc_s(s), rows, gamma, beta, scale,
+                       (long long)ss_bs, B, C, dgamma, dbeta, dscale, dshift);
+    return lc_launch_status();
+}
+
+extern "C" int lc_groupnorm_bwd_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                                     const float* mean_rstd, const float* gamma, const float* beta,
+                                     const float* scale, const float* shift, int64_t ss_bs, double* rows,
+                                     float* dx, int64_t dx_bs, int B, int C, int H, int W, int G,
+                                     int act_silu, float* amax_out, lc_stream_t s) {
     if (!x || !dy || !mean_rstd || !rows || !dx || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const long long HW = (long long)H * W;
     hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3(C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs, dy,
@@ -645,6 +725,15 @@ extern "C" int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, i
     if (slabs < 1) slabs = 1;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(slabs, C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
                        dy, (long long)dy_bs, mean_rstd, gamma, beta, scale, shift, (long long)ss_bs, rows,
-                       dx, (long long)dx_bs, C, G, HW, act_silu);
+                       dx, (long long)dx_bs, C, G, HW, act_silu, amax_out);
     return lc_launch_status();
+}
+
+extern "C" int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                                const float* mean_rstd, const float* gamma, const float* beta,
+                                const float* scale, const float* shift, int64_t ss_bs, double* rows,
+                                float* dx, int64_t dx_bs, int B, int C, int H, int W, int G,
+                                int act_silu, lc_stream_t s) {
+    return lc_groupnorm_bwd_amax(x, x_bs, dy, dy_bs, mean_rstd, gamma, beta, scale, shift, ss_bs, rows, dx, dx_bs, B,
+                                 C, H, W, G, act_silu, nullptr, s);
 }

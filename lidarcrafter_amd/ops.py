@@ -706,6 +706,47 @@ class PackedConv:
                   "lc_pack_conv_weight_f16x2")
         return self.wh, self.wl
 
+    def get_f16x2_dx(self, w_fwd: torch.Tensor, fwd: Optional["PackedConv"] = None):
+        """The packed weight of the INPUT-GRADIENT conv of the layer whose forward weight is `w_fwd` ([Cf_o, Cf_i, k, k]):
+        this record becomes a conv with Co = Cf_i, Ci = Cf_o (lc_pack_conv_weight_f16x2_dx: the rotated / transposed
+        weight is never materialised).  `fwd` = the layer's forward PackedConv: when it holds the pack of this very
+        weight version, its max|w| is reused."""
+        if isinstance(w_fwd, torch.Tensor) and w_fwd.dtype in _HALF:
+            w_fwd = w_fwd.float()
+        _req(w_fwd, "weight")
+        w = w_fwd.detach()
+        if w.dim() == 3:
+            w = w.unsqueeze(-1)
+        key = ("dx", w_fwd.data_ptr(), w_fwd._version, tuple(w.shape))
+        if key != self._key or self.wh is None:
+            Cfo, Cfi, kh, kw = w.shape
+            if kh != kw or kh not in (1, 3):
+                raise ValueError(f"only 1x1 / 3x3 kernels, got {tuple(w.shape)}")
+            self.Co, self.Ci, self.ks, self._key = Cfi, Cfo, kh, key
+            self._w4 = w.contiguous()
+            self.wp = None
+            n = lib().lc_packed_conv_weight_f16x2_elems(self.Co, self.Ci, self.ks)
+            both = torch.empty(2 * n, device=w.device, dtype=torch.float16)
+            self.wh, self.wl = both[:n], both[n:]
+            self.wmeta = torch.empty(4, device=w.device, dtype=_F32)
+            src = None
+            if fwd is not None and fwd.wh is not None and fwd.wmeta is not None and \
+                    fwd._key == (w_fwd.data_ptr(), w_fwd._version, tuple(w_fwd.shape)):
+                src = fwd.wmeta.data_ptr()
+            check(lib().lc_pack_conv_weight_f16x2_dx(self._w4.data_ptr(), self.wh.data_ptr(), self.wl.data_ptr(),
+                                                     self.Co, self.Ci, self.ks, self.wmeta.data_ptr(), src,
+                                                     _stream()), "lc_pack_conv_weight_f16x2_dx")
+        return self.wh, self.wl
+
+
+def range_from_amax(amax: torch.Tensor, packed: PackedConv, device, bound_mult: float = 1.0) -> None:
+    """`packed`'s input range record from the partial maxima of |x| the producer of x left (a contiguous fp32 tensor;
+    see lc_range_from_amax) -- the training graph's GroupNorm passes do (autograd.GroupNormAct)."""
+    ptr = packed.range_ptr(device)
+    packed._arena.device_managed.add(packed._slot)
+    check(lib().lc_range_from_amax(amax.data_ptr(), amax.numel(), float(bound_mult), ptr, _stream()),
+          "lc_range_from_amax")
+
 
 def range_from_tensor(x: torch.Tensor, packed: PackedConv) -> None:
     """Set `packed`'s input range record from max|x| ON THE DEVICE (lc_range_from_tensor): the next
@@ -730,7 +771,8 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                 out: Optional[torch.Tensor] = None, out_scale: float = 1.0,
                 tile_cfg: int = 0, precision: Optional[str] = None,
                 gn_coeffs: Optional[torch.Tensor] = None, gn_silu: bool = True,
-                emit_stats: bool = False) -> torch.Tensor:
+                emit_stats: bool = False, dx_of: Optional[PackedConv] = None,
+                weight_is_fwd: bool = False) -> torch.Tensor:
     """y = (conv_ring(x', W) + bias [+ res]) * out_scale with x' = x, or -- when `gn_coeffs`
     (from `groupnorm_coeffs`) is given -- x' = silu?(GroupNorm(x)) applied on the fly while the
     input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference.
@@ -741,7 +783,11 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     concat buffer whose halves both carry them) then skips its statistics pass.  Every wrapper of
     this module that writes into an `out=` tensor forgets the statistics of what it overwrites;
     a caller who modifies such a tensor with a torch in-place op must not request them (inference
-    tensors carry no version counter that could catch it)."""
+    tensors carry no version counter that could catch it).
+
+    weight_is_fwd (f16x2 only): `weight` is the FORWARD weight of the layer whose input gradient this call computes
+    (x = dY); the conv runs with its transposed, rotated kernel, packed in place by `PackedConv.get_f16x2_dx`
+    (dx_of = that layer's forward PackedConv, for its max|w|)."""
     if isinstance(x, SplitAct):
         return _conv2d_ring_presplit(x, packed, weight, bias, res, out, out_scale, tile_cfg,
                                      emit_stats)
@@ -749,8 +795,10 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     prec = precision or CONV_PRECISION
     if gn_coeffs is not None and prec != "f16x2":
         raise ValueError("fused input GroupNorm exists for the f16x2 conv kernels only")
+    if weight_is_fwd and prec != "f16x2":
+        raise ValueError("weight_is_fwd exists for the f16x2 kernels only")
     if prec == "f16x2":
-        wh, wl = packed.get_f16x2(weight)
+        wh, wl = packed.get_f16x2_dx(weight, dx_of) if weight_is_fwd else packed.get_f16x2(weight)
     else:
         wp = packed.get(weight)
     B, Ci, H, W = x.shape

@@ -108,6 +108,121 @@ def test_shared_conv_two_forwards_one_backward(dev):
     assert rel_l2(m.bias.grad, br.grad) < 2e-6
 
 
+@pytest.mark.parametrize("Co,Ci,ks", [(64, 64, 3), (130, 96, 3), (7, 5, 3), (32, 64, 1), (256, 128, 3)])
+@pytest.mark.parametrize("mag", [1.0, 1e-9, 3e7])
+def test_dx_weight_pack_is_the_pack_of_the_rotated_transpose(dev, Co, Ci, ks, mag):
+    """lc_pack_conv_weight_f16x2_dx (rotation + transposition in the addressing, max|w| taken from the forward pack or
+    measured) == lc_pack_conv_weight_f16x2 of the materialised flip(2, 3).transpose(0, 1): identical bytes and wmeta."""
+    from lidarcrafter_amd import ops as K
+
+    w = (seeded_randn(Co, Ci, ks, ks, seed=5) * mag).to(dev)
+    fwd, ref, a, b = (K.PackedConv(n) for n in ("t.fwd", "t.ref", "t.a", "t.b"))
+    fwd.get_f16x2(w)
+    rh, rl = ref.get_f16x2(w.flip(2, 3).transpose(0, 1).contiguous())
+    for pc, src in ((a, fwd), (b, None)):
+        h, l = pc.get_f16x2_dx(w, src)
+        assert (pc.Co, pc.Ci, pc.ks) == (Ci, Co, ks)
+        assert torch.equal(h.view(torch.int16), rh.view(torch.int16))
+        assert torch.equal(l.view(torch.int16), rl.view(torch.int16))
+        assert torch.equal(pc.wmeta[:3], ref.wmeta[:3]), (pc.wmeta, ref.wmeta)
+    # the same weight version is packed once; a new version (optimizer step) again
+    before = a.wh.data_ptr()
+    a.get_f16x2_dx(w, fwd)
+    assert a.wh.data_ptr() == before
+    w.mul_(0.5)
+    h2, _ = a.get_f16x2_dx(w, fwd)                      # fwd's pack is stale now: max|w| is measured, not borrowed
+    r2, _ = ref.get_f16x2(w.flip(2, 3).transpose(0, 1).contiguous())
+    assert torch.equal(h2.view(torch.int16), r2.view(torch.int16)) and torch.equal(a.wmeta[:3], ref.wmeta[:3])
+
+
+@pytest.mark.parametrize("B,C,H,W,G", [(2, 16, 4, 8, 8), (1, 64, 8, 128, 8), (3, 96, 5, 50, 32), (8, 64, 32, 1024, 8)])
+def test_producer_amax_records_equal_measured_records(dev, B, C, H, W, G):
+    """The range record set from the max|.| the GroupNorm forward / backward kernels publish == the record
+    lc_range_from_tensor measures on the tensor they wrote (same four floats), also after a dropout bound."""
+    from lidarcrafter_amd import autograd as AG
+    from lidarcrafter_amd import ops as K
+
+    class N:
+        num_groups, eps = G, 1e-5
+    n = N()
+    n.weight = (seeded_randn(C, seed=2) * 0.3 + 1).to(dev).requires_grad_()
+    n.bias = (seeded_randn(C, seed=3) * 0.2).to(dev).requires_grad_()
+    x = (seeded_randn(B, C, H, W, seed=1) * 3.7).to(dev).requires_grad_()
+    y = AG.group_norm(n, x, act=True)
+    m = AG._amax_of(y)
+    assert m is not None and m[1] == 1.0
+    assert float(m[0].max()) == float(y.detach().abs().max())
+    a, b = K.PackedConv("t.a"), K.PackedConv("t.b")
+    K.range_from_amax(m[0], a, dev)
+    K.range_from_tensor(y.detach(), b)
+    assert torch.equal(a.range_snapshot(dev), b.range_snapshot(dev))
+    # dropout keeps a bound; an in-place edit invalidates the tag
+    yd = AG.dropout(y, 0.25, True)
+    md = AG._amax_of(yd)
+    assert md is not None and abs(md[1] - 1 / 0.75) < 1e-12
+    assert float(yd.detach().abs().max()) <= float(m[0].max()) * md[1] * (1 + 1e-6)
+    assert AG.dropout(y, 0.0, True) is y and AG.dropout(y, 0.5, False) is y
+    # backward: the tag travels with dx to whatever consumes it
+    seen = {}
+
+    def hook(g):
+        seen["m"] = (AG._amax_of(g), float(g.abs().max()))
+
+    x.register_hook(hook)
+    (y * seeded_randn(B, C, H, W, seed=4).to(dev)).sum().backward()
+    assert seen["m"][0] is not None, "the gradient lost the producer's tag on its way through the engine"
+    assert float(seen["m"][0][0].max()) == seen["m"][1]
+    # views and the FIR resampling keep the tag (resampling: a convex combination per output sample)
+    assert AG._amax_of(AG._tok(y.detach().reshape(B, C, H * W))) is None      # a fresh tensor: nothing to carry
+    z = AG._carry_amax(y, y.reshape(B, C, 1, H * W))
+    assert AG._amax_of(z) is not None
+    if H % 2 == 0 and W % 2 == 0:
+        for up in (True, False):
+            r = AG.resample(y, up)
+            mr = AG._amax_of(r)
+            assert mr is not None and float(r.detach().abs().max()) <= float(mr[0].max()) * (1 + 1e-6)
+    t = y.detach().clone()
+    AG._tag_amax(t, m[0])
+    assert AG._amax_of(t) is not None
+    t.add_(1.0)
+    assert AG._amax_of(t) is None
+
+
+def test_producer_amax_route_is_taken_and_changes_nothing(dev, monkeypatch):
+    """The reduced EfficientUNet loss with the producer-amax hand-over on and off: bit-identical loss and gradients (the
+    records are the same numbers), and most range measurements -- every GroupNorm -> conv pair in the forward, every
+    conv -> GroupNorm pair in the backward -- no longer read their tensor."""
+    from lidarcrafter_amd import autograd as AG
+    from lidarcrafter_amd import ops as K
+    from tests.test_hip_parity import _uncond
+
+    m = _uncond(16, (8, 64), dev).train()
+    x = seeded_randn(2, 2, 8, 64, seed=31).to(dev)
+    lam = torch.tensor([0.3, -1.2], device=dev)
+    tgt = seeded_randn(2, 2, 8, 64, seed=32).to(dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(AG, "PRODUCER_AMAX", on)
+        calls = {"tensor": 0, "amax": 0}
+        rt, ra = K.range_from_tensor, K.range_from_amax
+        monkeypatch.setattr(K, "range_from_tensor", lambda *a, **k: (calls.__setitem__("tensor", calls["tensor"] + 1), rt(*a, **k))[1])
+        monkeypatch.setattr(K, "range_from_amax", lambda *a, **k: (calls.__setitem__("amax", calls["amax"] + 1), ra(*a, **k))[1])
+        m.zero_grad()
+        loss = ((m(x, lam) - tgt) ** 2).mean()
+        loss.backward()
+        res[on] = (float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}, dict(calls))
+        monkeypatch.setattr(K, "range_from_tensor", rt)
+        monkeypatch.setattr(K, "range_from_amax", ra)
+    assert res[True][0] == res[False][0]
+    for k, g in res[True][1].items():
+        assert torch.equal(g, res[False][1][k]), k
+    on, off = res[True][2], res[False][2]
+    assert off["amax"] == 0 and on["amax"] > 0
+    assert on["tensor"] + on["amax"] == off["tensor"]
+    assert on["amax"] >= off["tensor"] // 2, (on, off)
+    print(f"range records: {off['tensor']} measured -> {on['tensor']} measured + {on['amax']} handed over")
+
+
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks", [(8, 64, 64, 32, 1024, 3), (4, 128, 64, 16, 512, 3), (2, 192, 128, 8, 256, 1),
                                             (1, 34, 64, 32, 1024, 3), (2, 64, 2, 32, 1024, 3)])
 def test_split_weight_gradient_vs_exact_fp32(dev, B, Ci, Co, H, W, ks):
