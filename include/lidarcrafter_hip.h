@@ -37,6 +37,9 @@ typedef void* lc_stream_t;
 int lc_abi_version(void);
 /* Writes gcnArchName of the current device into buf (NUL terminated). */
 int lc_device_arch(char* buf, int buflen);
+/* Loads the code objects of every translation unit of the library for the CURRENT device now (HIP defers that to a
+ * unit's first kernel launch, i.e. into the first sampling step of a process).  Idempotent, no device work. */
+int lc_load_code_objects(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution: lidargen/models/unets/ops.py:149-173 (ops.Conv2d) with ops.py:32-49 (Pad,

@@ -44,6 +44,7 @@ class ConvRange(C.Structure):
 SIGNATURES = {
     "lc_abi_version": (i32, []),
     "lc_device_arch": (i32, [C.c_char_p, i32]),
+    "lc_load_code_objects": (i32, []),
     "lc_packed_conv_weight_elems": (i64, [i32, i32, i32]),
     "lc_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, vp]),
     "lc_conv2d_ring_fwd": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32,

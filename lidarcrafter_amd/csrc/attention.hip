@@ -486,3 +486,5 @@ extern "C" int lc_attention_train_fwd(const float* q, const float* k, const floa
     return attention_launch(f16x2, lse, &oq, nullptr, &ok, nullptr, &ov, nullptr, nullptr, nullptr, o, (int64_t)dv * Lq, 0, Lq,
                             BH, 1, Lq, Lk, 0, dqk, 0, dv, scale, s);
 }
+
+LC_TOUCH_TU(attention, attn_kernel<32, 1>)

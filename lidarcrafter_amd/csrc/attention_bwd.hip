@@ -254,3 +254,5 @@ extern "C" int lc_attention_bwd(const float* q, const float* k, const float* v, 
 #undef LC_BWD
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(attention_bwd, attn_dsum_kernel)

@@ -370,3 +370,5 @@ extern "C" int lc_attention_bwd_f16x2(const float* q, const float* k, const floa
 #undef LC_BWD
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(attention_bwd_h, attn_dsum_h_kernel)

@@ -64,3 +64,12 @@ __device__ __forceinline__ void lc_block_amax_store(float am, float* out) {
         *out = m;
     }
 }
+
+// Code-object warm-up (misc.hip: lc_load_code_objects): every translation unit names one of its kernels; asking the
+// runtime for that kernel's attributes makes it load the unit's code object for the current device now instead of
+// at the unit's first launch.
+#define LC_TOUCH_TU(name, ...)                                                                        \
+    extern "C" __attribute__((visibility("hidden"))) int lc_touch_##name() {                          \
+        hipFuncAttributes fa;                                                                         \
+        return (int)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&__VA_ARGS__));           \
+    }

@@ -295,3 +295,5 @@ extern "C" int lc_conv2d_ring_fwd(const float* x, int64_t x_bs, const float* wp,
     if (tile_cfg == 0) tile_cfg = auto_cfg(B, Co, H, W);
     return ks == 3 ? dispatch<3>(tile_cfg, a, lc_s(s)) : dispatch<1>(tile_cfg, a, lc_s(s));
 }
+
+LC_TOUCH_TU(conv, pack_weight_kernel)

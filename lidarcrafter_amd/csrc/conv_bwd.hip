@@ -498,3 +498,5 @@ extern "C" int lc_conv2d_ring_wgrad_f16x2(const float* x, int64_t x_bs, const fl
     }
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(conv_bwd, conv_wgrad_kernel<3>)

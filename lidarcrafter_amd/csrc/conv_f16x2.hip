@@ -2195,3 +2195,5 @@ extern "C" int lc_splitk_reduce(const float* part, int ksplit, const float* bias
                        (int)lc_splitk_stats_slots(H, W));
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(conv_f16x2, tensor_amax_kernel)

@@ -320,3 +320,5 @@ extern "C" int lc_points_in_boxes_mask4(const float* boxes, int n_boxes, const f
                        out_mask, out_count);
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(geometry, zbuf_clear_kernel)

@@ -116,3 +116,5 @@ extern "C" int lc_layout_condition(const void* boxes, int boxes_f64, int box_str
                        lc_s(s), rects, n_valid, T, H, W, condition_mask, loss_weight_map);
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(layout, paint_kernel)

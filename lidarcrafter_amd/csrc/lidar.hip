@@ -86,3 +86,5 @@ extern "C" int lc_condition_preprocess(const float* condition_mask, int64_t cm_b
                        (float)(1.0 / log2((double)max_depth + 1.0)));
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(lidar, postprocess_kernel)

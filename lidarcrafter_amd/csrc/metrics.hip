@@ -166,3 +166,5 @@ extern "C" int lc_chamfer3d_fwd(const float* xyz1, const float* xyz2, int B, int
                        dist2, idx2);
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(metrics, hist_clear_kernel)

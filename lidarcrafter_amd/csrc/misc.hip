@@ -163,6 +163,35 @@ inline int grid_for(long long n) {
 
 extern "C" int lc_abi_version(void) { return 2; }
 
+// Loads every translation unit's code object for the current device (HIP defers that to the unit's first launch; a
+// first sampling step otherwise pays ~15 loads).  Idempotent; lidarcrafter_amd.ops.prepare_model calls it.
+extern "C" {
+int lc_touch_attention();
+int lc_touch_attention_bwd();
+int lc_touch_attention_bwd_h();
+int lc_touch_conv();
+int lc_touch_conv_bwd();
+int lc_touch_conv_f16x2();
+int lc_touch_geometry();
+int lc_touch_layout();
+int lc_touch_lidar();
+int lc_touch_metrics();
+int lc_touch_norm();
+int lc_touch_resample();
+int lc_touch_roipool();
+int lc_touch_temporal();
+int lc_touch_voxel();
+}
+extern "C" int lc_load_code_objects(void) {
+    int (*const touch[])() = {lc_touch_attention, lc_touch_attention_bwd, lc_touch_attention_bwd_h, lc_touch_conv, lc_touch_conv_bwd, lc_touch_conv_f16x2, lc_touch_geometry, lc_touch_layout, lc_touch_lidar, lc_touch_metrics, lc_touch_norm, lc_touch_resample, lc_touch_roipool, lc_touch_temporal, lc_touch_voxel};
+    for (auto f : touch) {
+        const int rc = f();
+        if (rc != 0) return rc;
+    }
+    hipFuncAttributes fa;
+    return (int)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&linear_kernel<8>));
+}
+
 extern "C" int lc_device_arch(char* buf, int buflen) {
     if (!buf || buflen <= 0) return LC_EINVAL;
     int dev = 0;

@@ -737,3 +737,5 @@ extern "C" int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, i
     return lc_groupnorm_bwd_amax(x, x_bs, dy, dy_bs, mean_rstd, gamma, beta, scale, shift, ss_bs, rows, dx, dx_bs, B,
                                  C, H, W, G, act_silu, nullptr, s);
 }
+
+LC_TOUCH_TU(norm, gn_stats_kernel)

@@ -162,3 +162,5 @@ extern "C" int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t
     }
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(resample, down2_kernel)

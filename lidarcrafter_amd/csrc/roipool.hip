@@ -170,3 +170,5 @@ extern "C" int lc_roiaware_pool3d_bwd(const int32_t* pts_idx_of_voxels, const in
                        grad_out, grad_in, pool_method);
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(roipool, roi_mask_kernel)

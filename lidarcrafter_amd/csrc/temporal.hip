@@ -214,3 +214,5 @@ extern "C" int lc_compact_points(const float* rows, const int32_t* keep, int N, 
                            scratch, out, src_index);
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(temporal, transform_kernel)

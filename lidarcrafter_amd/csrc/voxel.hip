@@ -193,3 +193,5 @@ extern "C" int lc_sparse_quantize(const float* coords, int N, int D, float vx, f
         return lc_launch_status();
     return lc_launch_status();
 }
+
+LC_TOUCH_TU(voxel, bev_occupancy_kernel)

@@ -123,6 +123,10 @@ def setup_model(cfg: str, ckpt, device="cpu", ema: bool = True, show_info: bool 
     ddpm.eval().to(device)
     # `compile` is accepted for signature parity; the denoiser already runs hand-written kernels.
     lidar_utils = _lidar_utils(cfg, ddpm).to(device)
+    if torch.device(device).type == "cuda":
+        # one-time costs out of the first sampling step: conv weights packed, code objects loaded
+        from lidarcrafter_amd import ops as K
+        K.prepare_model(ddpm)
     if show_info:
         print(f"resolution: {model.resolution}", f"model: {model.__class__.__name__}",
               f"ddpm: {ddpm.__class__.__name__}", f'#steps:  {ckpt["global_step"]:,}',

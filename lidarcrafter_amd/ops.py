@@ -739,6 +739,39 @@ class PackedConv:
         return self.wh, self.wl
 
 
+def prepare_model(module: torch.nn.Module) -> int:
+    """Pay the one-time costs of `module`'s conv layers NOW instead of inside the first sampling step: pack every conv
+    weight that already lives on a GPU (the packs are cached per weight version, so the first forward finds them) and
+    load the library's code objects for that device (HIP loads a translation unit's kernels at its first launch).
+    Returns the number of weights packed.  lidargen.utils.inference.setup_model calls it for a model set up on a GPU."""
+    n = 0
+    dev = None
+    for m in module.modules():
+        d = m.__dict__
+        pairs = []
+        if isinstance(d.get("_packed"), PackedConv) and isinstance(getattr(m, "weight", None), torch.Tensor):
+            pairs.append((d["_packed"], m.weight))
+        if isinstance(d.get("_pk_in"), PackedConv):                      # SelfAttentionBlock: MHA projections as 1x1 convs
+            att = getattr(m, "attn", None)
+            if att is not None and getattr(att, "in_proj_weight", None) is not None:
+                pairs.append((d["_pk_in"], att.in_proj_weight[:, :, None, None]))
+                pairs.append((d["_pk_out"], att.out_proj.weight[:, :, None, None]))
+        for pk, w in pairs:
+            if not w.is_cuda or w.dim() not in (3, 4) or w.shape[-1] not in (1, 3):
+                continue
+            dev = w.device
+            with torch.cuda.device(dev):
+                if CONV_PRECISION == "f16x2":
+                    pk.get_f16x2(w)
+                else:
+                    pk.get(w)
+            n += 1
+    if dev is not None:
+        with torch.cuda.device(dev):
+            check(lib().lc_load_code_objects(), "lc_load_code_objects")
+    return n
+
+
 def range_from_amax(amax: torch.Tensor, packed: PackedConv, device, bound_mult: float = 1.0) -> None:
     """`packed`'s input range record from the partial maxima of |x| the producer of x left (a contiguous fp32 tensor;
     see lc_range_from_amax) -- the training graph's GroupNorm passes do (autograd.GroupNormAct)."""

@@ -580,6 +580,30 @@ def test_unet_full_golden(dev, golden, gn_stats_route):
     assert r < 2e-5, r
 
 
+def test_prepare_model_packs_every_conv_weight_once(dev, monkeypatch):
+    """ops.prepare_model (called by inference.setup_model on a GPU): every conv weight of the denoiser is packed and the
+    code objects are loaded up front; the first forward then packs nothing, and gives the bits of an unprepared model."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd._lib import lib
+
+    x = seeded_randn(2, 2, 8, 64, seed=23).to(dev)
+    lam = torch.tensor([-1.0, 0.7], device=dev)
+    with torch.no_grad():
+        ref = _uncond(16, (8, 64), dev)(x, lam).clone()
+    m = _uncond(16, (8, 64), dev)
+    n_conv = sum(1 for mod in m.modules() if isinstance(mod.__dict__.get("_packed"), K.PackedConv)) + \
+        2 * sum(1 for mod in m.modules() if isinstance(mod.__dict__.get("_pk_in"), K.PackedConv))
+    assert K.prepare_model(m) == n_conv > 40
+    assert lib().lc_load_code_objects() == 0            # idempotent
+    calls = []
+    real = lib().lc_pack_conv_weight_f16x2
+    monkeypatch.setattr(lib(), "lc_pack_conv_weight_f16x2", lambda *a: (calls.append(1), real(*a))[1])
+    with torch.no_grad():
+        y = m(x, lam)
+    assert not calls, f"{len(calls)} weights were packed again by the first forward"
+    assert torch.equal(y, ref)
+
+
 def test_unet_batch_invariance(dev):
     m = _uncond(16, (8, 64), dev)
     x = seeded_randn(3, 2, 8, 64, seed=23).to(dev)
