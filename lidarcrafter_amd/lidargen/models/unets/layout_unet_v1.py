@@ -116,50 +116,84 @@ class ObjectAwareCrossAttention(nn.Module):
                  use_key_padding_mask=False, channels_scale_for_positional_embedding=1.0,
                  norm_first=False, norm_for_obj_embedding=False):
         super().__init__()
-        if norm_first or norm_for_obj_embedding or use_key_padding_mask or \
-                channels_scale_for_positional_embedding != 1.0 or return_attention_embeddings:
-            raise NotImplementedError("HIP ObjectAwareCrossAttention implements the shipped "
-                                      "configuration (norm_first=False, no key padding mask)")
         assert use_positional_embedding and encoder_channels is not None
         self.type, self.ds, self.resolution, self.channels = type, ds, resolution, channels
+        # the options no shipped configuration sets (layout_unet_v1.py:367-376, 402-412): normalisation before the
+        # projectors, an extra norm of xf_out, positional channels = channels * scale, masked layout keys, and the
+        # positional operands handed back to a direct caller of the layer
+        self.norm_first = norm_first
+        self.channels_scale_for_positional_embedding = channels_scale_for_positional_embedding
+        self.use_key_padding_mask = use_key_padding_mask
+        self.return_attention_embeddings = return_attention_embeddings
         if num_head_channels == -1:
             self.num_heads = num_heads
         else:
             assert channels % num_head_channels == 0
             self.num_heads = channels // num_head_channels
         self.encoder_channels = encoder_channels
+        cpos = int(channels * channels_scale_for_positional_embedding)
+        self.pos_channels = cpos
+        if cpos % self.num_heads or (channels // self.num_heads) + cpos // self.num_heads > 64:
+            raise NotImplementedError(
+                f"HIP ObjectAwareCrossAttention: {cpos} positional channels over {self.num_heads} heads -- the attention "
+                "kernels take content + positional channels per head <= 64 in whole heads")
         self.qkv_projector = conv_nd(1, channels, 3 * channels, 1)
         self.norm_for_qkv = normalization(channels)
         self.layout_content_embedding_projector = conv_nd(1, encoder_channels, channels * 2, 1)
-        self.layout_position_embedding_projector = conv_nd(1, encoder_channels, channels, 1)
-        self.norm_for_obj_class_embedding = normalization(encoder_channels)
-        self.norm_for_layout_positional_embedding = normalization(channels)
-        self.norm_for_image_patch_positional_embedding = normalization(channels)
+        self.layout_position_embedding_projector = conv_nd(1, encoder_channels, cpos, 1)
+        self.norm_for_obj_embedding = None
+        if norm_first:
+            if norm_for_obj_embedding:
+                self.norm_for_obj_embedding = normalization(encoder_channels)
+            self.norm_for_obj_class_embedding = normalization(encoder_channels)
+            self.norm_for_layout_positional_embedding = normalization(encoder_channels)
+            self.norm_for_image_patch_positional_embedding = normalization(encoder_channels)
+        else:
+            self.norm_for_obj_class_embedding = normalization(encoder_channels)
+            self.norm_for_layout_positional_embedding = normalization(cpos)
+            self.norm_for_image_patch_positional_embedding = normalization(cpos)
         self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
         self._cond_cache = None
 
     def condition_operands(self, cond):
         """Step-invariant operands (reference recomputes them every step, :431-476)."""
         img = cond[f"image_patch_bbox_embedding_for_resolution{self.resolution}"]
+        mask = cond["key_padding_mask"] if self.use_key_padding_mask else None
         key = (img.data_ptr(), cond["obj_bbox_embedding"].data_ptr(), cond["xf_out"].data_ptr(),
                cond["obj_class_embedding"].data_ptr(), _ver(cond["xf_out"]),
                self.layout_position_embedding_projector.weight._version,
-               self.layout_content_embedding_projector.weight._version)
+               self.layout_content_embedding_projector.weight._version,
+               None if mask is None else (mask.data_ptr(), _ver(mask)))
         if self._cond_cache is None or self._cond_cache[0] != key:
             C = self.channels
-            pos_img = self.norm_for_image_patch_positional_embedding(
-                self.layout_position_embedding_projector(img))
-            pos_lay = self.norm_for_layout_positional_embedding(
-                self.layout_position_embedding_projector(cond["obj_bbox_embedding"]))
+            proj = self.layout_position_embedding_projector
+            if self.norm_first:                                     # :431-433, :457-459
+                pos_img = proj(self.norm_for_image_patch_positional_embedding(img))
+                pos_lay = proj(self.norm_for_layout_positional_embedding(cond["obj_bbox_embedding"]))
+            else:                                                   # :435-438, :461-462
+                pos_img = self.norm_for_image_patch_positional_embedding(proj(img))
+                pos_lay = self.norm_for_layout_positional_embedding(proj(cond["obj_bbox_embedding"]))
             cls = self.norm_for_obj_class_embedding(cond["obj_class_embedding"])
             B, E, L2 = cls.shape
-            content = K.add_scale(cond["xf_out"].reshape(B, E, 1, L2), cls.view(B, E, 1, L2), 0.5)
+            xf = cond["xf_out"] if self.norm_for_obj_embedding is None else self.norm_for_obj_embedding(cond["xf_out"])
+            content = K.add_scale(xf.reshape(B, E, 1, L2), cls.view(B, E, 1, L2), 0.5)
             kv = self.layout_content_embedding_projector(content.view(B, E, L2))
+            k_lay, v_lay = kv[:, :C], kv[:, C:]
+            per_sample = None
+            if mask is not None:
+                # masked_fill(-inf) before the softmax (:478-500) == those layout keys do not exist: every sample keeps
+                # its own set of valid keys (compacted once per condition; the image keys are never masked)
+                keep = (~mask.bool()).cpu()
+                per_sample = []
+                for b in range(B):
+                    idx = torch.nonzero(keep[b]).flatten().to(kv.device)
+                    per_sample.append(None if idx.numel() == 0 else tuple(
+                        t[b:b + 1].index_select(2, idx).contiguous() for t in (k_lay, v_lay, pos_lay)))
             # the keyed tensors are kept alive by the cache: their addresses cannot be handed to
             # a different condition while it is valid (versions are not tracked in inference mode)
-            hold = (img, cond["obj_bbox_embedding"], cond["xf_out"], cond["obj_class_embedding"])
-            self._cond_cache = (key, pos_img, pos_lay, kv[:, :C], kv[:, C:], hold)
-        return self._cond_cache[1:5]
+            hold = (img, cond["obj_bbox_embedding"], cond["xf_out"], cond["obj_class_embedding"], mask)
+            self._cond_cache = (key, pos_img, pos_lay, k_lay, v_lay, per_sample, hold)
+        return self._cond_cache[1:6]
 
     def forward(self, x, cond_kwargs, out=None):
         B, C, H, W = x.shape
@@ -168,19 +202,33 @@ class ObjectAwareCrossAttention(nn.Module):
             xs = K.alias(torch.as_strided(x, (B, C, L1), (x.stride(0), L1, 1)), x)
         else:
             xs = x.contiguous().view(B, C, L1)
-        pos_img, pos_lay, k_lay, v_lay = self.condition_operands(cond_kwargs)
+        pos_img, pos_lay, k_lay, v_lay, per_sample = self.condition_operands(cond_kwargs)
         if K.fuse_gn(3 * C):
             qkv = self.qkv_projector(xs, gn_coeffs=gn32_coeffs(self.norm_for_qkv, xs))
         else:
             qkv = self.qkv_projector(self.norm_for_qkv(xs))
         heads = self.num_heads
-        scale = 1.0 / math.sqrt(2 * C // heads)   # (q*s)(k*s) with s = (2C/h)^-1/4, :489-492
-        a = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale,
-                           k2=k_lay, v2=v_lay, q_pos=pos_img, k_pos=pos_img, k2_pos=pos_lay)
+        # (q*s)(k*s) with s = (((1 + scale_pos) C) / heads)^-1/4, :489-492
+        scale = 1.0 / math.sqrt(int((1 + self.channels_scale_for_positional_embedding) * C) // heads)
+        if per_sample is None:
+            a = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale,
+                               k2=k_lay, v2=v_lay, q_pos=pos_img, k_pos=pos_img, k2_pos=pos_lay)
+        else:
+            a = torch.empty((B, C, L1), device=x.device, dtype=torch.float32)
+            for b in range(B):
+                sl = slice(b, b + 1)
+                kl, vl, pl = per_sample[b] if per_sample[b] is not None else (None, None, None)
+                K.attention_cm(qkv[sl, :C], qkv[sl, C:2 * C], qkv[sl, 2 * C:], heads, scale, k2=kl, v2=vl,
+                               q_pos=pos_img[sl], k_pos=pos_img[sl], k2_pos=pl, out=a[sl])
         o3 = None if out is None else out
         # (statistics for the next block's GroupNorm: they follow the tensor through the token view)
         y = self.proj_out(a, res=xs, out=None if o3 is None else K.alias(_as3(o3), o3), emit_stats=True)
-        return (K.alias(y.view(B, C, H, W), y) if out is None else out), None
+        extra = None
+        if self.return_attention_embeddings:                        # :512-530
+            extra = {"type": self.type, "ds": self.ds, "resolution": self.resolution, "num_heads": heads,
+                     "num_channels": C, "image_query_embeddings": pos_img.detach().reshape(B, -1, L1),
+                     "layout_key_embeddings": pos_lay.detach().reshape(B, -1, pos_lay.shape[-1])}
+        return (K.alias(y.view(B, C, H, W), y) if out is None else out), extra
 
 
 def _ver(t):
@@ -201,18 +249,19 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
         """`scale_shifts`: iterator of precomputed (scale, shift) pairs for the ResBlocks inside;
         `out`: destination view for the LAST layer's result."""
         n = len(self)
+        extra = None                                 # layout_unet_v1.py:70-78: the last attention layer's extra output
         for i, layer in enumerate(self):
             o = out if i == n - 1 else None
             if isinstance(layer, ResBlock):
                 ss = next(scale_shifts) if scale_shifts is not None else None
                 x = layer(x, emb, scale_shift=ss, out=o)
             elif isinstance(layer, ObjectAwareCrossAttention):
-                x, _ = layer(x, cond_kwargs, out=o)
+                x, extra = layer(x, cond_kwargs, out=o)
             elif isinstance(layer, ops.Conv2d):      # the input convolution feeds the first block's norm
                 x = layer(x, out=o, emit_stats=_stats_unit(layer.out_channels))
             else:
                 x = layer(x, out=o)
-        return x, None
+        return x, extra
 
 
 class LayoutUnetV1(nn.Module):

@@ -197,18 +197,22 @@ def _ln(sd, pre, x):
     return F.layer_norm(x, x.shape[-1:], sd[pre + ".weight"], sd[pre + ".bias"], 1e-5)
 
 
-def _xf_attention(qkv, heads):
+def _xf_attention(qkv, heads, key_padding_mask=None):
+    """layout_encoder.py:67-84 (key_padding_mask [B, T] bool: True = padded key, :77-81)."""
     B, T, width = qkv.shape
     ch = width // heads // 3
     scale = 1 / math.sqrt(math.sqrt(ch))
     q, k, v = qkv.view(B, T, heads, -1).split(ch, dim=-1)
-    w = torch.einsum("bthc,bshc->bhts", q * scale, k * scale).softmax(-1)
+    w = torch.einsum("bthc,bshc->bhts", q * scale, k * scale)
+    if key_padding_mask is not None:
+        w = w.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    w = w.softmax(-1)
     return torch.einsum("bhts,bshc->bthc", w, v).reshape(B, T, -1)
 
 
 @torch.no_grad()
 def layout_encoder_forward(sd, batch, *, feature_map_size, resolution_to_attention, num_heads=4,
-                           prefix=""):
+                           prefix="", use_key_padding_mask=False):
     """-> the condition dict the denoiser consumes (layout_encoder.py:237-303, configuration
     used_condition_types=[obj_class,obj_bbox,is_valid_obj], no positional embedding, final LN)."""
     p = prefix
@@ -236,7 +240,8 @@ def layout_encoder_forward(sd, batch, *, feature_map_size, resolution_to_attenti
     while f"{p}transform.resblocks.{i}.ln_1.weight" in sd:
         q = f"{p}transform.resblocks.{i}"
         a = F.linear(_ln(sd, q + ".ln_1", x), sd[q + ".attn.c_qkv.weight"], sd[q + ".attn.c_qkv.bias"])
-        a = F.linear(_xf_attention(a, num_heads), sd[q + ".attn.c_proj.weight"],
+        a = F.linear(_xf_attention(a, num_heads, out["key_padding_mask"] if use_key_padding_mask else None),
+                     sd[q + ".attn.c_proj.weight"],
                      sd[q + ".attn.c_proj.bias"])
         x = x + a
         m = F.linear(_ln(sd, q + ".ln_2", x), sd[q + ".mlp.c_fc.weight"], sd[q + ".mlp.c_fc.bias"])
@@ -258,31 +263,49 @@ def _conv1d(sd, pre, x):
     return F.conv1d(x, sd[pre + ".weight"], sd[pre + ".bias"])
 
 
-def object_aware_attention(sd, pre, x, cond, resolution):
-    """layout_unet_v1.py:416-532 (norm_first=False, channels_scale_for_positional_embedding=1)."""
+def object_aware_attention(sd, pre, x, cond, resolution, opts=None):
+    """layout_unet_v1.py:416-532.  opts: the constructor options no shipped configuration sets (:367-376) --
+    {"norm_first": bool, "use_key_padding_mask": bool, "channels_scale_for_positional_embedding": float};
+    norm_for_obj_embedding is discovered from its keys."""
+    o = opts or {}
+    norm_first, use_mask = bool(o.get("norm_first")), bool(o.get("use_key_padding_mask"))
+    s_pos = float(o.get("channels_scale_for_positional_embedding", 1.0))
     B, C, H, W = x.shape
     heads = C // 32
     d = C // heads
     L1 = H * W
     xs = x.reshape(B, C, L1)
     qkv = _conv1d(sd, pre + ".qkv_projector", gn32(sd, pre + ".norm_for_qkv", xs))
-    pos_img = gn32(sd, pre + ".norm_for_image_patch_positional_embedding",
-                   _conv1d(sd, pre + ".layout_position_embedding_projector",
-                           cond[f"image_patch_bbox_embedding_for_resolution{resolution}"]))
-    pos_lay = gn32(sd, pre + ".norm_for_layout_positional_embedding",
-                   _conv1d(sd, pre + ".layout_position_embedding_projector",
-                           cond["obj_bbox_embedding"]))
-    content = (cond["xf_out"] + gn32(sd, pre + ".norm_for_obj_class_embedding",
-                                     cond["obj_class_embedding"])) / 2
+    img = cond[f"image_patch_bbox_embedding_for_resolution{resolution}"]
+    if norm_first:                                                       # :431-433, :457-459
+        pos_img = _conv1d(sd, pre + ".layout_position_embedding_projector",
+                          gn32(sd, pre + ".norm_for_image_patch_positional_embedding", img))
+        pos_lay = _conv1d(sd, pre + ".layout_position_embedding_projector",
+                          gn32(sd, pre + ".norm_for_layout_positional_embedding", cond["obj_bbox_embedding"]))
+    else:                                                                # :435-438, :461-462
+        pos_img = gn32(sd, pre + ".norm_for_image_patch_positional_embedding",
+                       _conv1d(sd, pre + ".layout_position_embedding_projector", img))
+        pos_lay = gn32(sd, pre + ".norm_for_layout_positional_embedding",
+                       _conv1d(sd, pre + ".layout_position_embedding_projector",
+                               cond["obj_bbox_embedding"]))
+    xf = cond["xf_out"]
+    if (pre + ".norm_for_obj_embedding.weight") in sd:                   # :466-467
+        xf = gn32(sd, pre + ".norm_for_obj_embedding", xf)
+    content = (xf + gn32(sd, pre + ".norm_for_obj_class_embedding", cond["obj_class_embedding"])) / 2
     k_lay, v_lay = _conv1d(sd, pre + ".layout_content_embedding_projector", content).split(C, 1)
-    hv = lambda t: t.reshape(B * heads, d, -1)
+    hv = lambda t: t.reshape(B * heads, -1, t.shape[-1])
     q, k, v = [hv(t) for t in qkv.split(C, dim=1)]
     pi, pl = hv(pos_img), hv(pos_lay)
     qm = torch.cat([q, pi], 1)
     km = torch.cat([torch.cat([k, pi], 1), torch.cat([hv(k_lay), pl], 1)], 2)
     vm = torch.cat([v, hv(v_lay)], 2)
-    scale = 1 / math.sqrt(math.sqrt(2 * d))
-    w = torch.einsum("bct,bcs->bts", qm * scale, km * scale).float().softmax(-1)
+    scale = 1 / math.sqrt(math.sqrt(int((1 + s_pos) * C) // heads))      # :489
+    w = torch.einsum("bct,bcs->bts", qm * scale, km * scale)
+    if use_mask:                                                         # :478-500
+        L2 = pl.shape[-1]
+        kpm = torch.cat([torch.zeros((B, L1), dtype=torch.bool), cond["key_padding_mask"].bool()], 1)
+        w = w.view(B, heads, L1, L1 + L2).masked_fill(kpm[:, None, None, :], float("-inf")).view(B * heads, L1, L1 + L2)
+    w = w.float().softmax(-1)
     a = torch.einsum("bts,bcs->bct", w, vm).reshape(B, C, L1)
     return (xs + _conv1d(sd, pre + ".proj_out", a)).reshape(B, C, H, W)
 
@@ -304,7 +327,7 @@ def res_block_v1(sd, pre, x, emb):
     return x + h
 
 
-def _run_sequential(sd, pre, h, emb, cond, image_size, ds):
+def _run_sequential(sd, pre, h, emb, cond, image_size, ds, attn_opts=None):
     """TimestepEmbedSequential (layout_unet_v1.py:63-78): children discovered from the keys."""
     i = 0
     while True:
@@ -314,7 +337,7 @@ def _run_sequential(sd, pre, h, emb, cond, image_size, ds):
             if (q + ".op.kernel") in sd:
                 ds = ds * 2 if float(sd[q + ".op.kernel"].sum()) < 1.5 else ds // 2
         elif (q + ".qkv_projector.weight") in sd:
-            h = object_aware_attention(sd, q, h, cond, image_size // ds)
+            h = object_aware_attention(sd, q, h, cond, image_size // ds, attn_opts)
         elif (q + ".weight") in sd and sd[q + ".weight"].ndim == 4:
             h = conv_sd(sd, q, h)
         else:
@@ -324,7 +347,7 @@ def _run_sequential(sd, pre, h, emb, cond, image_size, ds):
 
 
 @torch.no_grad()
-def layout_unet_v1_forward(sd, x, log_snr, cond, *, image_size, model_channels=64, prefix=""):
+def layout_unet_v1_forward(sd, x, log_snr, cond, *, image_size, model_channels=64, prefix="", attn_opts=None):
     """layout_unet_v1.py:866-902."""
     p = prefix
     B, _, H, W = x.shape
@@ -335,14 +358,14 @@ def layout_unet_v1_forward(sd, x, log_snr, cond, *, image_size, model_channels=6
     h = torch.cat([h, fourier_features(sd[p + "coords"], H, W).expand(B, -1, -1, -1)], dim=1)
     hs, ds, i = [], 1, 0
     while f"{p}input_blocks.{i}.0.weight" in sd or f"{p}input_blocks.{i}.0.in_layers.0.weight" in sd:
-        h, ds = _run_sequential(sd, f"{p}input_blocks.{i}", h, emb, cond, image_size, ds)
+        h, ds = _run_sequential(sd, f"{p}input_blocks.{i}", h, emb, cond, image_size, ds, attn_opts)
         hs.append(h)
         i += 1
-    h, ds = _run_sequential(sd, p + "middle_block", h, emb, cond, image_size, ds)
+    h, ds = _run_sequential(sd, p + "middle_block", h, emb, cond, image_size, ds, attn_opts)
     i = 0
     while f"{p}output_blocks.{i}.0.in_layers.0.weight" in sd:
         h = torch.cat([h, hs.pop()], dim=1)
-        h, ds = _run_sequential(sd, f"{p}output_blocks.{i}", h, emb, cond, image_size, ds)
+        h, ds = _run_sequential(sd, f"{p}output_blocks.{i}", h, emb, cond, image_size, ds, attn_opts)
         i += 1
     h = silu(gn32(sd, p + "out.0", h))
     return conv_sd(sd, p + "out.2", h)

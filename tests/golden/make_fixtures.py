@@ -212,7 +212,7 @@ def synth_layout_batch(B, H, W, seed, n_extra=0):
     return f(B, H, W, seed, n_extra)
 
 
-def _build_cond(res, image_size, model_channels, cond_out=10):
+def _build_cond(res, image_size, model_channels, cond_out=10, unet_kw=None, enc_kw=None):
     lu = R.ref("models.unets.layout_unet_v1")
     le = R.ref("models.unets.layout_encoder")
     lidar = R.ref("utils.lidar")
@@ -225,14 +225,15 @@ def _build_cond(res, image_size, model_channels, cond_out=10):
                             num_res_blocks=2, num_attention_blocks=1, resblock_updown=True,
                             attention_ds=[4, 8], channel_mult=[1, 2, 4, 8], dropout=0.1,
                             use_checkpoint=False, use_positional_embedding_for_attention=True,
-                            attention_block_type="ObjectAwareCrossAttention")
+                            attention_block_type="ObjectAwareCrossAttention", **(unet_kw or {}))
     m.coords = lidar.get_linear_ray_angles(res[0], res[1], 10.0, -30.0)
     enc = le.LayoutTransformerEncoder(
         feature_map_size=list(res), used_condition_types=["obj_class", "obj_bbox", "is_valid_obj"],
         layout_length=13, num_classes_for_layout_object=9, mask_size_for_layout_object=32,
         hidden_dim=64, output_dim=model_channels * 4, num_layers=6, num_heads=4, use_final_ln=True,
         use_positional_embedding=False, not_use_layout_fusion_module=False,
-        resolution_to_attention=[4, 8], use_key_padding_mask=False, out_channels=cond_out)
+        resolution_to_attention=[4, 8], out_channels=cond_out,
+        **{"use_key_padding_mask": False, **(enc_kw or {})})
     return seeded_fill(m, salt=200).eval(), seeded_fill(enc, salt=201).eval()
 
 
@@ -252,6 +253,35 @@ def sec_cond_small():
     out["keys_unet"] = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()))
     out["keys_enc"] = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in enc.state_dict().items()))
     save("cond_small", **out)
+
+
+# The ObjectAwareCrossAttention constructor options no shipped configuration sets (layout_unet_v1.py:367-376, 402-412)
+COND_OPTION_VARIANTS = {
+    "nf": ({"norm_first": True, "norm_for_obj_embedding": True, "channels_scale_for_positional_embedding": 0.5,
+            "use_key_padding_mask": True}, {"use_key_padding_mask": True}),
+    "mask": ({"use_key_padding_mask": True}, {}),
+    "scale": ({"channels_scale_for_positional_embedding": 0.5}, {}),
+}
+
+
+def sec_cond_options():
+    """Reduced LayoutUnetV1 + layout encoder with the unshipped attention options switched on, same seeded weights /
+    inputs as cond_small (the reference prints the padding mask in this path: stdout is swallowed)."""
+    import io, contextlib
+    out = {}
+    for tag, (ukw, ekw) in COND_OPTION_VARIANTS.items():
+        m, enc = _build_cond((8, 64), 8, 32, unet_kw=ukw, enc_kw=ekw)
+        batch = synth_layout_batch(2, 8, 64, seed=51)
+        x = seeded_randn(2, 2, 8, 64, seed=52)
+        lam = torch.tensor([-3.0, 1.5])
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            cond = enc(batch)
+            y = m(x, {"time_condition": lam, "other_condition": cond})
+        out[f"{tag}_y"] = y
+        out[f"{tag}_xf_out"] = cond["xf_out"]
+        out[f"{tag}_keys_unet"] = np.array(sorted(f"{k}:{tuple(v.shape)}" for k, v in m.state_dict().items()))
+        assert (1 - batch["is_valid_obj"]).bool().any(), "the batch must hold padded layout slots"
+    save("cond_options", **out)
 
 
 def sec_cond_full():

@@ -735,6 +735,49 @@ def test_cond_small_golden(dev, golden):
     assert r < 2e-5, r
 
 
+@pytest.mark.parametrize("tag", ["mask", "nf", "scale"])
+def test_cond_attention_options_golden(dev, golden, tag):
+    """The ObjectAwareCrossAttention constructor options no shipped configuration sets (normalisation before the
+    projectors, extra norm of xf_out, positional channels = channels / 2, masked layout keys -- also inside the layout
+    encoder) vs the reference's output (tests/golden/cond_options.npz)."""
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from tests.test_oracle_vs_golden import COND_OPTION_VARIANTS, build_cond_pair
+
+    g = golden("cond_options")
+    ukw, ekw = COND_OPTION_VARIANTS[tag]
+    m, enc = build_cond_pair((8, 64), 8, 32, unet_kw=ukw, enc_kw=ekw)
+    m, enc = m.to(dev), enc.to(dev)
+    batch = _to_dev(synth_layout_batch(2, 8, 64, seed=51), dev)
+    with torch.no_grad():
+        cond = enc(batch)
+        assert rel_l2(cond["xf_out"], T(g[tag + "_xf_out"])) < 5e-6
+        x = seeded_randn(2, 2, 8, 64, seed=52).to(dev)
+        lam = torch.tensor([-3.0, 1.5], device=dev)
+        y = m(x, {"time_condition": lam, "other_condition": cond})
+        y2 = m(x, {"time_condition": lam, "other_condition": cond})      # cached condition operands: same bits
+    r = rel_l2(y, T(g[tag + "_y"]))
+    assert r < 2e-5, r
+    assert torch.equal(y, y2)
+
+
+def test_cond_attention_extra_output(dev):
+    """return_attention_embeddings (layout_unet_v1.py:512-530): the layer hands its positional operands back."""
+    from lidargen.models.unets.layout_unet_v1 import ObjectAwareCrossAttention
+
+    at = seeded_fill(ObjectAwareCrossAttention(64, num_head_channels=32, encoder_channels=64, ds=4, resolution=2,
+                                               type="input", return_attention_embeddings=True), salt=9).to(dev).eval()
+    B, L1, L2 = 2, 2 * 16, 13
+    cond = {"image_patch_bbox_embedding_for_resolution2": seeded_randn(B, 64, L1, seed=1).to(dev),
+            "obj_bbox_embedding": seeded_randn(B, 64, L2, seed=2).to(dev),
+            "xf_out": seeded_randn(B, 64, L2, seed=3).to(dev),
+            "obj_class_embedding": seeded_randn(B, 64, L2, seed=4).to(dev)}
+    with torch.no_grad():
+        y, extra = at(seeded_randn(B, 64, 2, 16, seed=5).to(dev), cond)
+    assert y.shape == (B, 64, 2, 16)
+    assert extra["type"] == "input" and extra["ds"] == 4 and extra["resolution"] == 2 and extra["num_heads"] == 2
+    assert extra["image_query_embeddings"].shape == (B, 64, L1) and extra["layout_key_embeddings"].shape == (B, 64, L2)
+
+
 def test_cond_full_golden(dev, golden, gn_stats_route):
     """box-layout-v6 (70.1 M params) forward + 3-step conditional DDIM vs the reference."""
     from lidargen.utils import inference
