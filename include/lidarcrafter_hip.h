@@ -104,7 +104,7 @@ typedef struct lc_conv_range {
 int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t n, lc_conv_range* range,
                          lc_stream_t s);
 /* The same record from the partial maxima the PRODUCER of x left while writing it (amax: n device floats whose maximum is
- * max|x| -- lc_groupnorm_apply_amax / lc_groupnorm_bwd_amax store one per block, no atomics) -- one single-block launch,
+ * max|x| -- lc_groupnorm_apply_train / lc_groupnorm_bwd_train store one per block, no atomics) -- one single-block launch,
  * x is not read again.  bound_mult >= 1 (LC_EINVAL otherwise): the tensor the conv will read is an elementwise rescale of
  * the measured one by at most this factor (dropout: 1 / (1 - p)); max|x| * bound_mult is then an upper bound, which is
  * all the record needs. */
@@ -230,13 +230,15 @@ int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* partials, con
                        const float* beta, const float* scale, const float* shift, int64_t ss_bs,
                        float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
                        int act_silu, lc_stream_t s);
-/* ... and stores max|y| of every block of the pass into amax_out[0 .. lc_groupnorm_amax_partials(B, C, H, W, G, 0))
- * (may be NULL; every element is written, nothing to initialise) for lc_range_from_amax of the conv that consumes y. */
+/* The apply pass as the training graph runs it: additionally writes the (mean, rstd) it normalised with into
+ * mean_rstd_out [B, G, 2] (may be NULL; what lc_groupnorm_bwd* reads -- no lc_groupnorm_meanrstd launch) and stores max|y|
+ * of every block of the pass into amax_out[0 .. lc_groupnorm_amax_partials(B, C, H, W, G, 0)) (may be NULL; every
+ * element is written, nothing to initialise) for lc_range_from_amax of the conv that consumes y. */
 int64_t lc_groupnorm_amax_partials(int B, int C, int H, int W, int G, int backward);
-int lc_groupnorm_apply_amax(const float* x, int64_t x_bs, const double* partials, const float* gamma,
-                            const float* beta, const float* scale, const float* shift, int64_t ss_bs,
-                            float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
-                            int act_silu, float* amax_out, lc_stream_t s);
+int lc_groupnorm_apply_train(const float* x, int64_t x_bs, const double* partials, const float* gamma,
+                             const float* beta, const float* scale, const float* shift, int64_t ss_bs,
+                             float* y, int64_t y_bs, int B, int C, int H, int W, int G, float eps,
+                             int act_silu, float* mean_rstd_out, float* amax_out, lc_stream_t s);
 
 /* The same normalisation from the PRODUCER's octet statistics (lc_conv2d_ring_f16x2_fwd
  * gn_ostats_out): one launch, the tensor is read once.  A tensor may be the channel concatenation of
@@ -404,17 +406,15 @@ int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_b
                      const float* mean_rstd, const float* gamma, const float* beta, const float* scale,
                      const float* shift, int64_t ss_bs, double* rows, float* dx, int64_t dx_bs, int B,
                      int C, int H, int W, int G, int act_silu, lc_stream_t s);
-/* The parameter gradients from `rows` in one launch (fp64 arithmetic, fp32 results; any output may be NULL):
- * dgamma, dbeta [C]; dscale, dshift [B, C] contiguous.  gamma / beta / scale as passed to lc_groupnorm_bwd. */
-int lc_groupnorm_param_grads(const double* rows, const float* gamma, const float* beta, const float* scale,
-                             int64_t ss_bs, int B, int C, float* dgamma, float* dbeta, float* dscale,
-                             float* dshift, lc_stream_t s);
-/* ... and the partial maxima of |dx| into amax_out[0 .. lc_groupnorm_amax_partials(..., 1)) (as lc_groupnorm_apply_amax):
- * dx is the dY of the conv that produced x. */
-int lc_groupnorm_bwd_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
-                          const float* mean_rstd, const float* gamma, const float* beta, const float* scale,
-                          const float* shift, int64_t ss_bs, double* rows, float* dx, int64_t dx_bs, int B,
-                          int C, int H, int W, int G, int act_silu, float* amax_out, lc_stream_t s);
+/* lc_groupnorm_bwd plus, in the same two launches: the parameter gradients from `rows` (fp64 arithmetic, fp32 results;
+ * any of them may be NULL): dgamma, dbeta [C]; dscale, dshift [B, C] contiguous -- and the partial maxima of |dx| into
+ * amax_out[0 .. lc_groupnorm_amax_partials(..., 1)) (may be NULL; as lc_groupnorm_apply_train): dx is the dY of the conv
+ * that produced x. */
+int lc_groupnorm_bwd_train(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                           const float* mean_rstd, const float* gamma, const float* beta, const float* scale,
+                           const float* shift, int64_t ss_bs, double* rows, float* dx, int64_t dx_bs,
+                           float* dgamma, float* dbeta, float* dscale, float* dshift, int B, int C, int H, int W,
+                           int G, int act_silu, float* amax_out, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Voxel scatter of the weight-free metrics (lidargen/metrics/metric_utils.py).

@@ -73,8 +73,8 @@ SIGNATURES = {
     "lc_groupnorm_stats": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, vp]),
     "lc_groupnorm_apply": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
                                  i32, f32, i32, vp]),
-    "lc_groupnorm_apply_amax": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
-                                      i32, f32, i32, vp, vp]),
+    "lc_groupnorm_apply_train": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,
+                                       i32, f32, i32, vp, vp, vp]),
     "lc_groupnorm_apply_os": (i32, [vp, i64, _os, _os, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32,
                                     i32, i32, f32, i32, vp]),
     "lc_conv2d_ring_wgrad_scratch_elems": (i64, [i32, i32, i32, i32, i32, i32]),
@@ -84,9 +84,8 @@ SIGNATURES = {
     "lc_groupnorm_meanrstd": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "lc_groupnorm_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32,
                                i32, i32, i32, vp]),
-    "lc_groupnorm_param_grads": (i32, [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
-    "lc_groupnorm_bwd_amax": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32,
-                                    i32, i32, i32, vp, vp]),
+    "lc_groupnorm_bwd_train": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp,
+                                     i32, i32, i32, i32, i32, i32, vp, vp]),
     "lc_resample2x_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
     "lc_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "lc_sinusoid_fwd": (i32, [vp, vp, i32, i32, f32, vp]),

@@ -12,9 +12,10 @@ training takes a second, plain composition of the same layers in which every hea
                          kernel (forward kernel; its weight packed straight from the forward weight,
                          lc_pack_conv_weight_f16x2_dx);  dW, db: lc_conv2d_ring_wgrad[_f16x2] (MFMA implicit
                          GEMM over pixels, deterministic two-stage reduction)
-  GroupNormAct  forward  lc_groupnorm_stats + lc_groupnorm_apply_amax (+ AdaGN scale/shift, + SiLU; leaves the
-                         partial maxima of |y| for the range record of the conv that consumes y)
-                backward lc_groupnorm_bwd_amax (rows + dx, partial maxima of |dx|) + lc_groupnorm_param_grads
+  GroupNormAct  forward  lc_groupnorm_stats + lc_groupnorm_apply_train (+ AdaGN scale/shift, + SiLU; leaves (mean,
+                         rstd) for the backward and the partial maxima of |y| for the range record of the conv
+                         that consumes y)
+                backward lc_groupnorm_bwd_train (rows + dx, the parameter gradients, partial maxima of |dx|)
   Resample2x    forward  lc_resample2x_fwd;  backward: the adjoint FIR = the opposite resampling
                          (down^T = up / 4, up^T = 4 down: same window, ring / zero padding)
 
@@ -138,10 +139,12 @@ def _bs(t):
 
 
 class ConvRing(torch.autograd.Function):
-    """y = conv_ring(x, W) + b (3x3: W circular / H zero padding, 1x1: plain)."""
+    """y = (conv_ring(x, W) + b [+ res]) * out_scale (3x3: W circular / H zero padding, 1x1: plain).  The residual add
+    and the 1/sqrt(2) of a block's exit run in the conv's epilogue, as in the inference forward; the backward
+    differentiates g = dy * out_scale through the conv and hands g to `res`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, holder, amax=None):
+    def forward(ctx, x, weight, bias, holder, amax=None, res=None, out_scale=1.0):
         x = _c4(x)
         x_rec = None
         if TRAIN_CONV_PRECISION == "f16x2":
@@ -152,15 +155,22 @@ class ConvRing(torch.autograd.Function):
             # the record x was measured with, kept with the saved activation: the same module may run forward again
             # (shared weights, two forwards feeding one loss) before this backward and re-measure the live record
             x_rec = holder["fwd"].range_snapshot(x.device)
-        y = K.conv2d_ring(x, holder["fwd"], weight, bias, precision=TRAIN_CONV_PRECISION)
+        y = K.conv2d_ring(x, holder["fwd"], weight, bias, res=None if res is None else _c4(res),
+                          out_scale=float(out_scale), precision=TRAIN_CONV_PRECISION)
         ctx.save_for_backward(x, weight)
         ctx.holder, ctx.has_bias, ctx.x_rec = holder, bias is not None, x_rec
+        ctx.out_scale, ctx.has_res = float(out_scale), res is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy_amax = _amax_of(dy) if PRODUCER_AMAX else None      # of the tensor as its producer handed it over
+        if ctx.out_scale != 1.0:
+            dy = dy * ctx.out_scale                             # the gradient of everything inside the parentheses
+            if dy_amax is not None:
+                dy_amax = (dy_amax[0], dy_amax[1] * max(1.0, abs(ctx.out_scale)))     # a bound, never below the truth
+        d_res = dy if ctx.has_res and ctx.needs_input_grad[5] else None
         dy = _c4(dy)
         B, Ci, H, W = x.shape
         Co, ks = weight.shape[0], weight.shape[-1]
@@ -202,17 +212,18 @@ class ConvRing(torch.autograd.Function):
                                                      scratch.data_ptr(), dw.data_ptr(),
                                                      None if db is None else db.data_ptr(), B, Ci, Co, H,
                                                      W, ks, 0, st), "lc_conv2d_ring_wgrad")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, d_res, None
 
 
-def conv(module, x):
-    """Differentiable call of an ops.Conv2d / PointwiseConv1d-like module (weight [Co,Ci,k,k])."""
+def conv(module, x, res=None, out_scale=1.0):
+    """Differentiable call of an ops.Conv2d / PointwiseConv1d-like module (weight [Co,Ci,k,k]):
+    (conv(x) + bias [+ res]) * out_scale."""
     holder = module.__dict__.get("_train_packed")
     if holder is None:
         holder = {"fwd": K.PackedConv("train.fwd"), "bwd": K.PackedConv("train.bwd")}
         module.__dict__["_train_packed"] = holder
     w = module.weight if module.weight.dim() == 4 else module.weight[:, :, :, None]
-    return ConvRing.apply(x, w, module.bias, holder, _amax_of(x) if PRODUCER_AMAX else None)
+    return ConvRing.apply(x, w, module.bias, holder, _amax_of(x) if PRODUCER_AMAX else None, res, out_scale)
 
 
 class FlashAttention(torch.autograd.Function):
@@ -280,12 +291,12 @@ class GroupNormAct(torch.autograd.Function):
             st = torch.cuda.current_stream().cuda_stream
             check(lib().lc_groupnorm_stats(x.data_ptr(), _bs(x), part.data_ptr(), B, C, H, W, G, st),
                   "lc_groupnorm_stats")
-            check(lib().lc_groupnorm_meanrstd(x.data_ptr(), _bs(x), part.data_ptr(), mr.data_ptr(), B,
-                                              C, H, W, G, float(eps), st), "lc_groupnorm_meanrstd")
             slot = _amax_slot(dev, B, C, H, W, G, False) if PRODUCER_AMAX and TRAIN_CONV_PRECISION == "f16x2" else None
-            check(lib().lc_groupnorm_apply_amax(x.data_ptr(), _bs(x), part.data_ptr(), p(gamma), p(beta),
-                                                p(sc), p(sf), C, y.data_ptr(), C * H * W, B, C, H, W, G,
-                                                float(eps), int(act), p(slot), st), "lc_groupnorm_apply_amax")
+            # apply pass; it also leaves the (mean, rstd) it used for the backward and the partial maxima of |y|
+            check(lib().lc_groupnorm_apply_train(x.data_ptr(), _bs(x), part.data_ptr(), p(gamma), p(beta),
+                                                 p(sc), p(sf), C, y.data_ptr(), C * H * W, B, C, H, W, G,
+                                                 float(eps), int(act), mr.data_ptr(), p(slot), st),
+                  "lc_groupnorm_apply_train")
         ctx.save_for_backward(x, mr, gamma, beta, sc, sf)
         ctx.G, ctx.act = G, act
         ctx.amax_slot = slot             # the tag itself is set on the tensor apply() returns (group_norm below)
@@ -302,14 +313,9 @@ class GroupNormAct(torch.autograd.Function):
         with torch.cuda.device(x.device):
             slot = _amax_slot(x.device, B, C, H, W, ctx.G, True) \
                 if PRODUCER_AMAX and TRAIN_CONV_PRECISION == "f16x2" else None
-            check(lib().lc_groupnorm_bwd_amax(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), mr.data_ptr(),
-                                              p(gamma), p(beta), p(sc), p(sf), C, rows.data_ptr(),
-                                              dx.data_ptr(), C * H * W, B, C, H, W, ctx.G, int(ctx.act), p(slot),
-                                              torch.cuda.current_stream().cuda_stream), "lc_groupnorm_bwd_amax")
-            if slot is not None:
-                _tag_amax(dx, slot)      # dx is the dY of the conv that produced x (when nothing else consumed x)
-            # the small parameter gradients from the rows: one launch (dshift = r1, dscale = g r3 + be r1,
-            # dbeta = sum_b (1 + sc) r1, dgamma = sum_b (1 + sc) r3; fp64 arithmetic)
+            # rows + dx, and in the same launches: the small parameter gradients from the rows (dshift = r1,
+            # dscale = g r3 + be r1, dbeta = sum_b (1 + sc) r1, dgamma = sum_b (1 + sc) r3; fp64 arithmetic) and the
+            # partial maxima of |dx|
             dgamma = dbeta = dscale = dshift = None
             if gamma is not None:
                 dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
@@ -317,11 +323,13 @@ class GroupNormAct(torch.autograd.Function):
             if sc is not None:
                 dscale = torch.empty((B, C), device=x.device, dtype=torch.float32)
                 dshift = torch.empty((B, C), device=x.device, dtype=torch.float32)
-            if gamma is not None or sc is not None:
-                check(lib().lc_groupnorm_param_grads(rows.data_ptr(), p(gamma), p(beta), p(sc), C, B, C, p(dgamma),
-                                                     p(dbeta), p(dscale), p(dshift),
-                                                     torch.cuda.current_stream().cuda_stream),
-                      "lc_groupnorm_param_grads")
+            check(lib().lc_groupnorm_bwd_train(x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), mr.data_ptr(),
+                                               p(gamma), p(beta), p(sc), p(sf), C, rows.data_ptr(),
+                                               dx.data_ptr(), C * H * W, p(dgamma), p(dbeta), p(dscale), p(dshift),
+                                               B, C, H, W, ctx.G, int(ctx.act), p(slot),
+                                               torch.cuda.current_stream().cuda_stream), "lc_groupnorm_bwd_train")
+            if slot is not None:
+                _tag_amax(dx, slot)      # dx is the dY of the conv that produced x (when nothing else consumed x)
             if beta is None:
                 dbeta = None
             if sf is None:
@@ -386,9 +394,8 @@ def efficient_unet_forward(m, images: torch.Tensor, log_snr: torch.Tensor) -> to
             h = group_norm(rb.norm2, h, act=True, scale=ss[:, :C], shift=ss[:, C:])
         else:
             h = group_norm(rb.norm2, h, act=True)
-        h = conv(rb.conv2, h)
         sk = x if isinstance(rb.skip, torch.nn.Identity) else conv(rb.skip, x)
-        return (sk + h) * rb._scale_f
+        return conv(rb.conv2, h, res=sk, out_scale=rb._scale_f)          # (skip + h) / sqrt(2) in the epilogue
 
     def attn_block(sa, x):
         B_, C, H, W = x.shape
@@ -397,8 +404,8 @@ def efficient_unet_forward(m, images: torch.Tensor, log_snr: torch.Tensor) -> to
                  group_norm(sa.norm, x))
         q = q.view(B_, 3, heads, C // heads, H * W)
         o = flash_attention(q[:, 0], q[:, 1], q[:, 2], (C // heads) ** -0.5).reshape(B_, C, H, W)
-        o = conv(_LinearAsConv(sa.attn.out_proj.weight, sa.attn.out_proj.bias, sa, "out"), o)
-        return (x + o) * sa._scale_f
+        return conv(_LinearAsConv(sa.attn.out_proj.weight, sa.attn.out_proj.bias, sa, "out"), o, res=x,
+                    out_scale=sa._scale_f)
 
     def block(blk, h):
         if not isinstance(blk.downsample, torch.nn.Identity):
@@ -496,9 +503,8 @@ def layout_unet_v1_forward(m, x: torch.Tensor, cond_dict: dict) -> torch.Tensor:
         C = rb.out_channels
         h = group_norm(rb.out_layers[0], h, act=True, scale=e[:, :C], shift=e[:, C:])
         h = dropout(h, rb.dropout, rb.training)
-        h = conv(rb.out_layers[3], h)
         sk = x if isinstance(rb.skip_connection, torch.nn.Identity) else conv(rb.skip_connection, x)
-        return sk + h
+        return conv(rb.out_layers[3], h, res=sk)
 
     def attention(at, x):
         B_, C, H_, W_ = x.shape
@@ -524,8 +530,8 @@ def layout_unet_v1_forward(m, x: torch.Tensor, cond_dict: dict) -> torch.Tensor:
         a = flash_attention(torch.cat([q, pi], dim=2),
                             torch.cat([torch.cat([k, pi], dim=2), torch.cat([kl, pl], dim=2)], dim=3),
                             torch.cat([v, vl], dim=3), s2)
-        out = xs + _conv_tok(at.proj_out, a.reshape(B_, C, L1))
-        return out.reshape(B_, C, H_, W_)
+        # x + proj_out(attention): the residual add in the projection's epilogue
+        return conv(at.proj_out, a.reshape(B_, C, H_, W_), res=x)
 
     def seq(blk, h):
         for layer in blk:

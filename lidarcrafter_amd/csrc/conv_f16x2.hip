@@ -1972,8 +1972,8 @@ extern "C" int lc_range_from_tensor(const float* x, int64_t x_bs, int B, int64_t
     return lc_launch_status();
 }
 
-// The record from the partial maxima some PRODUCER of x left while writing it (lc_groupnorm_apply_amax /
-// lc_groupnorm_bwd_amax: one float per block of the pass) -- the extra read of x by lc_range_from_tensor disappears.
+// The record from the partial maxima some PRODUCER of x left while writing it (lc_groupnorm_apply_train /
+// lc_groupnorm_bwd_train: one float per block of the pass) -- the extra read of x by lc_range_from_tensor disappears.
 // bound_mult >= 1: x is a known elementwise contraction / rescale of the measured tensor (dropout: 1 / (1 - p)).
 extern "C" int lc_range_from_amax(const float* amax, int64_t n, float bound_mult, lc_conv_range* range, lc_stream_t s) {
     if (!amax || n <= 0 || !range || !(bound_mult >= 1.0f)) return LC_EINVAL;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     const float* __restrict__ x, long long x_bs, const double* __restrict__ part,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
     const float* __restrict__ shift, long long ss_bs, float* __restrict__ y, long long y_bs, int C,
-    int G, long long HW, int nch, float eps, int act, int cpb, float* amax_out) {
+    int G, long long HW, int nch, float eps, int act, int cpb, float* mr_out, float* amax_out) {
     const int c_first = blockIdx.y * cpb, b = blockIdx.z;     // cpb channels of ONE group per block
     float am = 0.0f;                                          // max |y| of this thread (amax_out != NULL)
     const int cpg = C / G, g = c_first / cpg;
@@ -73,6 +73,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mu = (float)((double)x[b * x_bs + (long long)g * cpg * HW] + dm);
+    // training: the (mean, rstd) this pass normalised with, for the backward (the group's first block writes them)
+    if (mr_out && blockIdx.x == 0 && c_first == g * cpg && threadIdx.x == 0) {
+        mr_out[2 * (b * G + g)] = mu;
+        mr_out[2 * (b * G + g) + 1] = rstd;
+    }
     const long long per = (HW + gridDim.x - 1) / gridDim.x;
     const long long lo = blockIdx.x * per;
     const long long hi = lo + per < HW ? lo + per : HW;
@@ -310,8 +315,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ scale, const float* __restrict__ shift, long long ss_bs,
     const double* __restrict__ rows, float* __restrict__ dx, long long dx_bs, int C, int G,
-    long long HW, int act, float* amax_out) {
+    long long HW, int act, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dscale,
+    float* __restrict__ dshift, int B, float* amax_out) {
     const int c = blockIdx.y, b = blockIdx.z, cpg = C / G, g = c / cpg;
+    // The small parameter gradients from the rows (fp64, samples in ascending order: deterministic), by the first slab's
+    // thread 0:  dshift[b,c] = r1,  dscale[b,c] = g r3 + be r1;  the b = 0 block: dbeta[c] = sum_b (1 + sc) r1,
+    // dgamma[c] = sum_b (1 + sc) r3.
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double gd = gamma ? (double)gamma[c] : 1.0, bd = beta ? (double)beta[c] : 0.0;
+        if (dscale || dshift) {
+            const double r1 = rows[2 * ((long long)b * C + c)], r3 = rows[2 * ((long long)b * C + c) + 1];
+            if (dscale) dscale[(long long)b * C + c] = (float)(gd * r3 + bd * r1);
+            if (dshift) dshift[(long long)b * C + c] = (float)r1;
+        }
+        if (b == 0 && (dgamma || dbeta)) {
+            double ag = 0.0, ab = 0.0;
+            for (int bb = 0; bb < B; ++bb) {
+                const double one_sc = scale ? 1.0 + (double)scale[bb * ss_bs + c] : 1.0;
+                ab += one_sc * rows[2 * ((long long)bb * C + c)];
+                ag += one_sc * rows[2 * ((long long)bb * C + c) + 1];
+            }
+            if (dgamma) dgamma[c] = (float)ag;
+            if (dbeta) dbeta[c] = (float)ab;
+        }
+    }
     const float mu = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
     double m1 = 0.0, m2 = 0.0;                                  // group means of dxh and dxh * xh
     for (int k = 0; k < cpg; ++k) {
@@ -536,7 +563,7 @@ inline void gn_apply_grid(int B, int C, int G, long long HW, int* slabs, int* cp
 }
 }  // namespace
 
-// floats lc_groupnorm_apply_amax (backward == 0) / lc_groupnorm_bwd_amax (backward != 0) write through amax_out: one
+// floats lc_groupnorm_apply_train (backward == 0) / lc_groupnorm_bwd_train (backward != 0) write through amax_out: one
 // partial maximum per block of their apply pass
 extern "C" int64_t lc_groupnorm_amax_partials(int B, int C, int H, int W, int G, int backward) {
     if (B <= 0 || C <= 0 || G <= 0 || C % G || H <= 0 || W <= 0) return 0;
@@ -545,11 +572,11 @@ extern "C" int64_t lc_groupnorm_amax_partials(int B, int C, int H, int W, int G,
     return (int64_t)slabs * (backward ? C : C / cpb) * B;
 }
 
-extern "C" int lc_groupnorm_apply_amax(const float* x, int64_t x_bs, const double* partials,
-                                       const float* gamma, const float* beta, const float* scale,
-                                       const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B,
-                                       int C, int H, int W, int G, float eps, int act_silu,
-                                       float* amax_out, lc_stream_t s) {
+extern "C" int lc_groupnorm_apply_train(const float* x, int64_t x_bs, const double* partials,
+                                        const float* gamma, const float* beta, const float* scale,
+                                        const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B,
+                                        int C, int H, int W, int G, float eps, int act_silu,
+                                        float* mean_rstd_out, float* amax_out, lc_stream_t s) {
     if (!x || !y || !partials || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const long long HW = (long long)H * W;
     const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
@@ -557,7 +584,7 @@ extern "C" int lc_groupnorm_apply_amax(const float* x, int64_t x_bs, const doubl
     gn_apply_grid(B, C, G, HW, &slabs, &cpb);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(slabs, C / cpb, B), dim3(256), 0, lc_s(s), x,
                        (long long)x_bs, partials, gamma, beta, scale, shift, (long long)ss_bs, y,
-                       (long long)y_bs, C, G, HW, nch, eps, act_silu, cpb, amax_out);
+                       (long long)y_bs, C, G, HW, nch, eps, act_silu, cpb, mean_rstd_out, amax_out);
     return lc_launch_status();
 }
 
@@ -566,8 +593,8 @@ extern "C" int lc_groupnorm_apply(const float* x, int64_t x_bs, const double* pa
                                   const float* shift, int64_t ss_bs, float* y, int64_t y_bs, int B,
                                   int C, int H, int W, int G, float eps, int act_silu,
                                   lc_stream_t s) {
-    return lc_groupnorm_apply_amax(x, x_bs, partials, gamma, beta, scale, shift, ss_bs, y, y_bs, B, C, H, W, G, eps,
-                                   act_silu, nullptr, s);
+    return lc_groupnorm_apply_train(x, x_bs, partials, gamma, beta, scale, shift, ss_bs, y, y_bs, B, C, H, W, G, eps,
+                                    act_silu, nullptr, nullptr, s);
 }
 
 
@@ -678,44 +705,12 @@ extern "C" int lc_groupnorm_meanrstd(const float* x, int64_t x_bs, const double*
     return lc_launch_status();
 }
 
-// The small parameter gradients of GroupNorm(+AdaGN) from the rows of lc_groupnorm_bwd, one thread per channel, fp64,
-// samples in ascending order (deterministic):  dshift[b,c] = r1,  dscale[b,c] = g r3 + be r1,
-// dbeta[c] = sum_b (1 + sc) r1,  dgamma[c] = sum_b (1 + sc) r3.
-__global__ void gn_param_grads_kernel(const double* __restrict__ rows, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, const float* __restrict__ scale,
-                                      long long ss_bs, int B, int C, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, float* __restrict__ dscale,
-                                      float* __restrict__ dshift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
-    double ag = 0.0, ab = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const double r1 = rows[2 * ((long long)b * C + c)], r3 = rows[2 * ((long long)b * C + c) + 1];
-        const double one_sc = scale ? 1.0 + (double)scale[b * ss_bs + c] : 1.0;
-        ag += one_sc * r3;
-        ab += one_sc * r1;
-        if (dscale) dscale[(long long)b * C + c] = (float)(g * r3 + be * r1);
-        if (dshift) dshift[(long long)b * C + c] = (float)r1;
-    }
-    if (dgamma) dgamma[c] = (float)ag;
-    if (dbeta) dbeta[c] = (float)ab;
-}
-
-extern "C" int lc_groupnorm_param_grads(const double* rows, const float* gamma, const float* beta,
-                                        const float* scale, int64_t ss_bs, int B, int C, float* dgamma,
-                                        float* dbeta, float* dscale, float* dshift, lc_stream_t s) {
-    if (!rows || B <= 0 || C <= 0) return LC_EINVAL;
-    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, lc_s(s), rows, gamma, beta, scale,
-                       (long long)ss_bs, B, C, dgamma, dbeta, dscale, dshift);
-    return lc_launch_status();
-}
-
-extern "C" int lc_groupnorm_bwd_amax(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
-                                     const float* mean_rstd, const float* gamma, const float* beta,
-                                     const float* scale, const float* shift, int64_t ss_bs, double* rows,
-                                     float* dx, int64_t dx_bs, int B, int C, int H, int W, int G,
-                                     int act_silu, float* amax_out, lc_stream_t s) {
+extern "C" int lc_groupnorm_bwd_train(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs,
+                                      const float* mean_rstd, const float* gamma, const float* beta,
+                                      const float* scale, const float* shift, int64_t ss_bs, double* rows,
+                                      float* dx, int64_t dx_bs, float* dgamma, float* dbeta, float* dscale,
+                                      float* dshift, int B, int C, int H, int W, int G, int act_silu,
+                                      float* amax_out, lc_stream_t s) {
     if (!x || !dy || !mean_rstd || !rows || !dx || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const long long HW = (long long)H * W;
     hipLaunchKernelGGL(gn_bwd_rows_kernel, dim3(C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs, dy,
@@ -725,7 +720,7 @@ extern "C" int lc_groupnorm_bwd_amax(const float* x, int64_t x_bs, const float* 
     if (slabs < 1) slabs = 1;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(slabs, C, B), dim3(256), 0, lc_s(s), x, (long long)x_bs,
                        dy, (long long)dy_bs, mean_rstd, gamma, beta, scale, shift, (long long)ss_bs, rows,
-                       dx, (long long)dx_bs, C, G, HW, act_silu, amax_out);
+                       dx, (long long)dx_bs, C, G, HW, act_silu, dgamma, dbeta, dscale, dshift, B, amax_out);
     return lc_launch_status();
 }
 
@@ -734,8 +729,8 @@ extern "C" int lc_groupnorm_bwd(const float* x, int64_t x_bs, const float* dy, i
                                 const float* scale, const float* shift, int64_t ss_bs, double* rows,
                                 float* dx, int64_t dx_bs, int B, int C, int H, int W, int G,
                                 int act_silu, lc_stream_t s) {
-    return lc_groupnorm_bwd_amax(x, x_bs, dy, dy_bs, mean_rstd, gamma, beta, scale, shift, ss_bs, rows, dx, dx_bs, B,
-                                 C, H, W, G, act_silu, nullptr, s);
+    return lc_groupnorm_bwd_train(x, x_bs, dy, dy_bs, mean_rstd, gamma, beta, scale, shift, ss_bs, rows, dx, dx_bs,
+                                  nullptr, nullptr, nullptr, nullptr, B, C, H, W, G, act_silu, nullptr, s);
 }
 
 LC_TOUCH_TU(norm, gn_stats_kernel)

@@ -47,6 +47,38 @@ def test_conv_gradients(dev, B, Ci, Co, H, W, ks):
     assert rel_l2(m.bias.grad, br.grad) < 2e-6
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W,ks,scale", [(2, 64, 64, 4, 64, 3, 0.7071067811865476), (2, 96, 32, 6, 96, 1, 1.0),
+                                                  (1, 5, 7, 4, 16, 3, 0.5)])
+def test_conv_with_residual_and_scale_gradients(dev, B, Ci, Co, H, W, ks, scale):
+    """(conv(x) + b + res) * out_scale with the add and the scale in the conv's epilogue: y and the gradients of x, W,
+    b and res vs autograd of the oracle composition."""
+    from lidarcrafter_amd import autograd as AG
+    from oracle import denoiser as D
+
+    x = seeded_randn(B, Ci, H, W, seed=1)
+    w = seeded_randn(Co, Ci, ks, ks, seed=2) / (Ci * ks * ks) ** 0.5
+    b = seeded_randn(Co, seed=3)
+    r = seeded_randn(B, Co, H, W, seed=5)
+    g = seeded_randn(B, Co, H, W, seed=4)
+    ref = [t.clone().requires_grad_() for t in (x, w, b, r)]
+    yr = (D.conv_ring(ref[0], ref[1], ref[2]) + ref[3]) * scale
+    yr.backward(g)
+
+    class M:
+        pass
+
+    m = M()
+    m.weight = w.to(dev).requires_grad_()
+    m.bias = b.to(dev).requires_grad_()
+    xd, rd = x.to(dev).requires_grad_(), r.to(dev).requires_grad_()
+    y = AG.conv(m, xd, res=rd, out_scale=scale)
+    y.backward(g.to(dev))
+    assert rel_l2(y, yr) < 2e-6
+    for got, want, name in ((xd.grad, ref[0].grad, "dx"), (m.weight.grad, ref[1].grad, "dw"),
+                            (m.bias.grad, ref[2].grad, "db"), (rd.grad, ref[3].grad, "dres")):
+        assert rel_l2(got, want) < 2e-6, (name, rel_l2(got, want))
+
+
 @pytest.mark.parametrize("B,h,dqk,dv,Lq,Lk", [(2, 4, 32, 32, 100, 113), (1, 8, 64, 32, 512, 525), (1, 2, 16, 16, 64, 64),
                                               (2, 3, 24, 40, 33, 257), (1, 8, 64, 32, 2048, 2061), (1, 16, 32, 32, 512, 512)])
 @pytest.mark.parametrize("fwd,bwd", [("f16x2", "f16x2"), ("f32", "f32"), ("f16x2", "f32")])
