@@ -85,6 +85,21 @@ int lc_pack_conv_weight_f16x2(const float* w_oihw, void* wp_hi, void* wp_lo, int
  * (lidarcrafter_amd/autograd.py ConvRing.backward). */
 int lc_pack_conv_weight_f16x2_dx(const float* w_fwd, void* wp_hi, void* wp_lo, int Co, int Ci, int ks,
                                  float* wmeta, const float* wmeta_fwd, lc_stream_t s);
+/* All conv weights of a model at once (training: every weight changes at every optimizer step -- two packs per layer
+ * and step): `jobs` is a DEVICE array of n records; each names a forward weight w [Co][Ci][ks][ks] (contiguous), the
+ * buffers of its own pack (as lc_pack_conv_weight_f16x2: planes of lc_packed_conv_weight_f16x2_elems(Co, Ci, ks)
+ * halves, fwd_meta 4 floats) and, when with_dx != 0, of its input-gradient pack (as lc_pack_conv_weight_f16x2_dx:
+ * planes of lc_packed_conv_weight_f16x2_elems(Ci, Co, ks) halves, dx_meta 4 floats).  Three launches in total, same
+ * bytes as the per-layer functions. */
+typedef struct lc_weight_pack_job {
+    const float* w;
+    void *fwd_hi, *fwd_lo;
+    float* fwd_meta;
+    void *dx_hi, *dx_lo;
+    float* dx_meta;
+    int Co, Ci, ks, reserved;
+} lc_weight_pack_job;
+int lc_pack_conv_weights_f16x2_multi(const lc_weight_pack_job* jobs, int n, int with_dx, lc_stream_t s);
 /* Range state of ONE conv layer's input (device memory, 16 bytes, owned by the caller, initialise
  * with {16, 1/16, 0, 0}).  The kernel multiplies x by x_scale before the fp16 hi/lo split and
  * publishes the largest |x * x_scale| it staged (after the fused input GroupNorm, if any) into

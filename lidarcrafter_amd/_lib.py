@@ -52,6 +52,7 @@ SIGNATURES = {
     "lc_packed_conv_weight_f16x2_elems": (i64, [i32, i32, i32]),
     "lc_pack_conv_weight_f16x2": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "lc_pack_conv_weight_f16x2_dx": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "lc_pack_conv_weights_f16x2_multi": (i32, [vp, i32, i32, vp]),
     "lc_range_from_amax": (i32, [vp, i64, f32, vp, vp]),
     "lc_groupnorm_amax_partials": (i64, [i32, i32, i32, i32, i32, i32]),
     "lc_conv2d_ring_f16x2_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32,

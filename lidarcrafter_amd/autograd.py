@@ -72,6 +72,15 @@ def training_active(module: torch.nn.Module, *tensors) -> bool:
 # trusts the tag only while version and address still match -- the autograd engine may accumulate a second gradient into
 # the same tensor in place, which bumps the version.
 PRODUCER_AMAX = os.environ.get("LC_TRAIN_PRODUCER_AMAX", "1") != "0"
+# every conv weight of the training graph packed in three launches per optimizer step (ops.TrainWeightPlan) instead of
+# per layer; "0" keeps the per-layer packing
+MULTI_WEIGHT_PACK = os.environ.get("LC_TRAIN_MULTI_WEIGHT_PACK", "1") != "0"
+
+
+def begin_training_forward(device) -> None:
+    """Start of a forward through the training graph: weights that an optimizer step moved are packed now, all at once."""
+    if MULTI_WEIGHT_PACK and TRAIN_CONV_PRECISION == "f16x2":
+        K.train_weight_plan(device).refresh()
 
 
 def _amax_slot(device, B, C, H, W, G, backward: bool) -> torch.Tensor:
@@ -223,6 +232,8 @@ def conv(module, x, res=None, out_scale=1.0):
         holder = {"fwd": K.PackedConv("train.fwd"), "bwd": K.PackedConv("train.bwd")}
         module.__dict__["_train_packed"] = holder
     w = module.weight if module.weight.dim() == 4 else module.weight[:, :, :, None]
+    if MULTI_WEIGHT_PACK and TRAIN_CONV_PRECISION == "f16x2" and w.requires_grad:
+        K.train_weight_plan(w.device).register(w, holder)
     return ConvRing.apply(x, w, module.bias, holder, _amax_of(x) if PRODUCER_AMAX else None, res, out_scale)
 
 
@@ -374,6 +385,7 @@ def efficient_unet_forward(m, images: torch.Tensor, log_snr: torch.Tensor) -> to
     efficient_unet.py:274-300) on the Functions above; same parameters, same arithmetic order as the
     reference modules (GN -> SiLU -> conv -> AdaGN -> SiLU -> conv, (skip + h) / sqrt(2), ...)."""
     B = images.shape[0]
+    begin_training_forward(images.device)
     if log_snr.dim() == 0:
         log_snr = log_snr[None].repeat_interleave(B, dim=0)
     te = m.time_embedding
@@ -479,6 +491,7 @@ def layout_unet_v1_forward(m, x: torch.Tensor, cond_dict: dict) -> torch.Tensor:
                                       "the inference forward implements the other constructor options")
     lay = cond_dict["other_condition"]
     B, _, H, W = x.shape
+    begin_training_forward(x.device)
     t = cond_dict["time_condition"]
     if t.dim() == 0:
         t = t[None].repeat_interleave(B, dim=0)

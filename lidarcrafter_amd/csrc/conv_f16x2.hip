@@ -1834,18 +1834,11 @@ __device__ __forceinline__ float weight_scale_for(float amax) {
 // (wt[co][ci][tap] = w[ci][co][ntap-1-tap]), read in place: no flipped / transposed copy exists; amax_src (may be
 // NULL) = the wmeta of the forward pack of the same weight version, whose max|w| is this one's too.
 template <bool DX>
-__global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __restrict__ ph,
-                                     _Float16* __restrict__ pl, int Co, int Ci, int ntap, int Cib,
-                                     int Cop, float* wmeta, const float* __restrict__ amax_src) {
-    const float amax = amax_src ? amax_src[2] : wmeta[2];
-    const float ws = weight_scale_for(amax);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        wmeta[0] = ws; wmeta[1] = 1.0f / ws;
-        if (amax_src) { wmeta[2] = amax; wmeta[3] = 0.0f; }
-    }
+__device__ __forceinline__ void pack_weight_elems(const float* __restrict__ w, _Float16* __restrict__ ph,
+                                                  _Float16* __restrict__ pl, int Co, int Ci, int ntap, int Cib,
+                                                  int Cop, float ws, long long first, long long stride) {
     const long long n = (long long)ntap * Cib * Cop * 8;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n;
-         e += (long long)gridDim.x * blockDim.x) {
+    for (long long e = first; e < n; e += stride) {
         const int k = e & 7;
         long long r = e >> 3;
         const int co = r % Cop; r /= Cop;
@@ -1860,6 +1853,53 @@ __global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __re
         const float hf = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
         ph[e] = (_Float16)hf;
         pl[e] = (_Float16)(v - hf);
+    }
+}
+
+template <bool DX>
+__global__ void pack_weight_h_kernel(const float* __restrict__ w, _Float16* __restrict__ ph,
+                                     _Float16* __restrict__ pl, int Co, int Ci, int ntap, int Cib,
+                                     int Cop, float* wmeta, const float* __restrict__ amax_src) {
+    const float amax = amax_src ? amax_src[2] : wmeta[2];
+    const float ws = weight_scale_for(amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wmeta[0] = ws; wmeta[1] = 1.0f / ws;
+        if (amax_src) { wmeta[2] = amax; wmeta[3] = 0.0f; }
+    }
+    pack_weight_elems<DX>(w, ph, pl, Co, Ci, ntap, Cib, Cop, ws, blockIdx.x * (long long)blockDim.x + threadIdx.x,
+                          (long long)gridDim.x * blockDim.x);
+}
+
+// ---- all conv weights of a model in three launches (training: every weight changes at every optimizer step) ----------
+__global__ void multi_weight_zero_kernel(const lc_weight_pack_job* __restrict__ jobs, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) jobs[j].fwd_meta[2] = 0.0f;
+}
+__global__ void multi_weight_amax_kernel(const lc_weight_pack_job* __restrict__ jobs) {
+    const lc_weight_pack_job jb = jobs[blockIdx.y];
+    const long long n = (long long)jb.Co * jb.Ci * jb.ks * jb.ks;
+    float am = 0.0f;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        am = fmaxf(am, fabsf(jb.w[e]));
+    lc_block_amax_publish(am, reinterpret_cast<unsigned*>(jb.fwd_meta + 2));
+}
+// blockIdx.z = 0: the layer's own packed weight; 1: the packed weight of its input-gradient conv (Co / Ci swapped)
+__global__ void multi_weight_pack_kernel(const lc_weight_pack_job* __restrict__ jobs) {
+    const lc_weight_pack_job jb = jobs[blockIdx.y];
+    const float amax = jb.fwd_meta[2];
+    const float ws = weight_scale_for(amax);
+    const int ntap = jb.ks * jb.ks;
+    const long long first = blockIdx.x * (long long)blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (blockIdx.z == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { jb.fwd_meta[0] = ws; jb.fwd_meta[1] = 1.0f / ws; }
+        pack_weight_elems<false>(jb.w, (_Float16*)jb.fwd_hi, (_Float16*)jb.fwd_lo, jb.Co, jb.Ci, ntap,
+                                 (jb.Ci + 15) / 16 * 2, (jb.Co + 63) / 64 * 64, ws, first, stride);
+    } else {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            jb.dx_meta[0] = ws; jb.dx_meta[1] = 1.0f / ws; jb.dx_meta[2] = amax; jb.dx_meta[3] = 0.0f;
+        }
+        pack_weight_elems<true>(jb.w, (_Float16*)jb.dx_hi, (_Float16*)jb.dx_lo, jb.Ci, jb.Co, ntap,
+                                (jb.Co + 15) / 16 * 2, (jb.Ci + 63) / 64 * 64, ws, first, stride);
     }
 }
 
@@ -1896,6 +1936,15 @@ int pack_weight_h(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci, int 
 extern "C" int lc_pack_conv_weight_f16x2(const float* w, void* wp_hi, void* wp_lo, int Co, int Ci,
                                          int ks, float* wmeta, lc_stream_t s) {
     return pack_weight_h(w, wp_hi, wp_lo, Co, Ci, ks, wmeta, nullptr, false, s);
+}
+
+// Every job's forward pack and (with_dx) input-gradient pack in three launches; `jobs` is a DEVICE array.
+extern "C" int lc_pack_conv_weights_f16x2_multi(const lc_weight_pack_job* jobs, int n, int with_dx, lc_stream_t s) {
+    if (!jobs || n <= 0) return LC_EINVAL;
+    hipLaunchKernelGGL(multi_weight_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, lc_s(s), jobs, n);
+    hipLaunchKernelGGL(multi_weight_amax_kernel, dim3(16, n), dim3(256), 0, lc_s(s), jobs);
+    hipLaunchKernelGGL(multi_weight_pack_kernel, dim3(48, n, with_dx ? 2 : 1), dim3(256), 0, lc_s(s), jobs);
+    return lc_launch_status();
 }
 
 // Packed weight of the INPUT-GRADIENT conv of a layer, straight from the layer's forward weight w_fwd [Cf_o][Cf_i][ks][ks]:

@@ -739,6 +739,84 @@ class PackedConv:
         return self.wh, self.wl
 
 
+class TrainWeightPlan:
+    """All conv weights of the training graph packed in THREE launches per optimizer step (lc_pack_conv_weights_f16x2_multi)
+    instead of ~5 per layer: every layer registers (forward weight, its forward and input-gradient PackedConv) the first
+    time it runs; from the next step on `refresh()` -- called at the start of a training forward -- notices that weights
+    moved on, packs all of them into per-layer buffers that stay put, and primes the PackedConv caches, so the
+    per-layer `get_f16x2` / `get_f16x2_dx` calls of that step find their packs valid."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}            # id(holder) -> entry
+        self.table = None            # device array of lc_weight_pack_job
+        self.order = []
+
+    @staticmethod
+    def _base(w: torch.Tensor) -> torch.Tensor:
+        return w._base if w._base is not None else w
+
+    def register(self, w4: torch.Tensor, holder: dict) -> None:
+        if id(holder) in self.entries or not w4.is_cuda or w4.dtype != _F32:
+            return
+        base = self._base(w4)
+        if not base.is_contiguous() or base.data_ptr() != w4.data_ptr() or base.numel() != w4.numel():
+            return                                   # a strided / partial view: the per-layer route packs it
+        import weakref
+        Co, Ci, ks, _ = w4.shape
+        nf = int(lib().lc_packed_conv_weight_f16x2_elems(Co, Ci, ks))
+        nd = int(lib().lc_packed_conv_weight_f16x2_elems(Ci, Co, ks))
+        buf = torch.empty(2 * nf + 2 * nd, device=w4.device, dtype=torch.float16)
+        meta = torch.zeros(8, device=w4.device, dtype=_F32)
+        self.entries[id(holder)] = dict(
+            base=weakref.ref(base), fwd=holder["fwd"], bwd=holder["bwd"],
+            shape=(Co, Ci, ks, ks), ptr=base.data_ptr(), fh=buf[:nf], fl=buf[nf:2 * nf], dh=buf[2 * nf:2 * nf + nd],
+            dl=buf[2 * nf + nd:], fmeta=meta[:4], dmeta=meta[4:], buf=buf, meta=meta, packed_version=None)
+        self.table = None
+
+    def refresh(self) -> int:
+        """Pack every registered weight if any of them changed since its last pack; returns the number packed."""
+        dead = [k for k, e in self.entries.items() if e["base"]() is None or e["base"]().data_ptr() != e["ptr"]]
+        for k in dead:
+            del self.entries[k]
+            self.table = None
+        if not self.entries:
+            return 0
+        if all(e["base"]()._version == e["packed_version"] for e in self.entries.values()):
+            return 0
+        if self.table is None:
+            import struct
+            self.order = list(self.entries.values())
+            raw = b"".join(struct.pack("<7Q4i", e["ptr"], e["fh"].data_ptr(), e["fl"].data_ptr(), e["fmeta"].data_ptr(),
+                                       e["dh"].data_ptr(), e["dl"].data_ptr(), e["dmeta"].data_ptr(),
+                                       e["shape"][0], e["shape"][1], e["shape"][2], 0) for e in self.order)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        with torch.cuda.device(self.device):
+            check(lib().lc_pack_conv_weights_f16x2_multi(self.table.data_ptr(), len(self.order), 1, _stream()),
+                  "lc_pack_conv_weights_f16x2_multi")
+        for e in self.order:
+            base = e["base"]()
+            Co, Ci, ks, _ = e["shape"]
+            ver = base._version
+            e["packed_version"] = ver
+            f, b = e["fwd"], e["bwd"]
+            f.Co, f.Ci, f.ks, f._key = Co, Ci, ks, (e["ptr"], ver, e["shape"])
+            f._w4, f.wp, f.wh, f.wl, f.wmeta = base.detach().view(e["shape"]), None, e["fh"], e["fl"], e["fmeta"]
+            b.Co, b.Ci, b.ks, b._key = Ci, Co, ks, ("dx", e["ptr"], ver, e["shape"])
+            b._w4, b.wp, b.wh, b.wl, b.wmeta = f._w4, None, e["dh"], e["dl"], e["dmeta"]
+        return len(self.order)
+
+
+_train_weight_plans = {}
+
+
+def train_weight_plan(device) -> TrainWeightPlan:
+    plan = _train_weight_plans.get(device)
+    if plan is None:
+        plan = _train_weight_plans[device] = TrainWeightPlan(device)
+    return plan
+
+
 def prepare_model(module: torch.nn.Module) -> int:
     """Pay the one-time costs of `module`'s conv layers NOW instead of inside the first sampling step: pack every conv
     weight that already lives on a GPU (the packs are cached per weight version, so the first forward finds them) and

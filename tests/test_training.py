@@ -220,6 +220,54 @@ def test_producer_amax_records_equal_measured_records(dev, B, C, H, W, G):
     assert AG._amax_of(t) is None
 
 
+def test_multi_weight_pack_is_taken_and_changes_nothing(dev, monkeypatch):
+    """Two training steps (forward, backward, AdamW) of the reduced EfficientUNet with every conv weight packed in three
+    launches per step (ops.TrainWeightPlan) and with the per-layer packing: bit-identical losses and parameters, and from
+    the second step on no per-layer pack launch at all."""
+    from lidarcrafter_amd import autograd as AG
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd._lib import lib
+    from tests.test_hip_parity import _uncond
+
+    x = seeded_randn(2, 2, 8, 64, seed=31).to(dev)
+    lam = torch.tensor([0.3, -1.2], device=dev)
+    tgt = seeded_randn(2, 2, 8, 64, seed=32).to(dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(AG, "MULTI_WEIGHT_PACK", on)
+        m = _uncond(16, (8, 64), dev).train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+        calls = {"layer": 0, "multi": 0}
+        real = {n: getattr(lib(), n) for n in ("lc_pack_conv_weight_f16x2", "lc_pack_conv_weight_f16x2_dx",
+                                               "lc_pack_conv_weights_f16x2_multi")}
+        for n, key in (("lc_pack_conv_weight_f16x2", "layer"), ("lc_pack_conv_weight_f16x2_dx", "layer"),
+                       ("lc_pack_conv_weights_f16x2_multi", "multi")):
+            monkeypatch.setattr(lib(), n, (lambda f, k: lambda *a: (calls.__setitem__(k, calls[k] + 1), f(*a))[1])(real[n], key))
+        losses, per_step = [], []
+        for step in range(3):
+            before = dict(calls)
+            opt.zero_grad(set_to_none=True)
+            loss = ((m(x, lam) - tgt) ** 2).mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            per_step.append({k: calls[k] - before[k] for k in calls})
+        if on:      # a second forward before the next optimizer step (gradient accumulation) packs nothing
+            c0 = calls["multi"]
+            m(x, lam), m(x, lam)
+            assert calls["multi"] == c0 + 1 and K.train_weight_plan(dev).refresh() == 0
+        for n, f in real.items():
+            monkeypatch.setattr(lib(), n, f)
+        res[on] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()}, per_step)
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    for k, p in res[True][1].items():
+        assert torch.equal(p, res[False][1][k]), k
+    on, off = res[True][2], res[False][2]
+    assert all(s["multi"] == 0 and s["layer"] > 50 for s in off)
+    assert on[0]["layer"] == off[0]["layer"] and on[0]["multi"] == 0        # first step: layers register as they run
+    assert all(s == {"layer": 0, "multi": 1} for s in on[1:]), on
+
+
 def test_producer_amax_route_is_taken_and_changes_nothing(dev, monkeypatch):
     """The reduced EfficientUNet loss with the producer-amax hand-over on and off: bit-identical loss and gradients (the
     records are the same numbers), and most range measurements -- every GroupNorm -> conv pair in the forward, every
