@@ -1,5 +1,5 @@
 """Time the pre-split 3x3 conv (GroupNorm-apply output as hi / lo planes -> LDS-DMA kernel) on the C2 layer shapes.
-    LC_HIP_LIB=<variant> python devtools/ps_time.py [B]"""
+    LC_HIP_LIB=<variant> python devtools/ps_time.py [B] [--cfg N]"""
 import os
 import sys
 import time
@@ -9,7 +9,9 @@ import torch  # noqa: E402
 
 from lidarcrafter_amd import ops as K  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 0
+pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--cfg"]
+B = int(pos[0]) if pos else 8
 dev = torch.device("cuda:0")
 for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 128), (256, 128, 16, 512)):
     x = torch.randn(B, Ci, H, W, device=dev)
@@ -20,7 +22,7 @@ for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 12
     out = torch.empty(B, Co, H, W, device=dev)
     sa = K.groupnorm(x, 8, 1e-6, act_silu=True, split_for=pk)
     assert isinstance(sa, K.SplitAct)
-    f = lambda: K.conv2d_ring(sa, pk, w, b, out=out, res=res, out_scale=0.7071, emit_stats=True)
+    f = lambda: K.conv2d_ring(sa, pk, w, b, out=out, res=res, out_scale=0.7071, emit_stats=True, tile_cfg=cfg)
     for _ in range(3):
         f()
     g = torch.cuda.CUDAGraph()
@@ -36,4 +38,4 @@ for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 12
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 20)
     fl = 2.0 * B * H * W * Ci * Co * 9
-    print(f"ps {B}:{Ci}:{Co}:{H}:{W}: {min(ts) * 1e6:.1f} us  {fl / min(ts) / 1e12:.0f} TF")
+    print(f"ps {B}:{Ci}:{Co}:{H}:{W} cfg {cfg}: {min(ts) * 1e6:.1f} us  {fl / min(ts) / 1e12:.0f} TF")
