@@ -25,7 +25,7 @@ struct lc_conv_range { float x_scale, x_unscale, amax_scaled, reserved; };
 namespace {
 
 #ifndef CAND_NBUF
-#define CAND_NBUF 3     // LDS chunk buffers: 2 = the next chunk lands under this chunk's MFMAs, 3 = prefetch distance of two chunks
+#define CAND_NBUF 2     // LDS chunk buffers: 2 = the next chunk lands under this chunk's MFMAs (measured 2-6 % ahead), 3 = prefetch distance of two chunks
 #endif
 constexpr int BN = 128, BP = 256, CBK = 4, NT = 512, NBUF = CAND_NBUF;
 constexpr int XS = CBK * BP, WS = CBK * BN;            // units per plane per buffer
