@@ -39,17 +39,19 @@ from . import ops as K
 from ._lib import check, lib
 
 # arithmetic of the forward / dX convolutions inside the training graph: "f16x2" = the split kernels
-# (fp32-class accuracy; the pre-scale of every operand -- activation or gradient -- is measured on
-# the device right before its conv, K.range_from_tensor), "f32" = exact-fp32 MFMA kernels.
+# (fp32-class accuracy; the pre-scale of every operand -- activation or gradient -- comes from max|.| of that very
+# tensor, measured on the device right before its conv (K.range_from_tensor) or left behind by the GroupNorm pass that
+# wrote it (K.range_from_amax)), "f32" = exact-fp32 MFMA kernels.
 TRAIN_CONV_PRECISION = os.environ.get("LC_TRAIN_CONV_PRECISION", "f16x2")
 # ... and of the weight gradient: "f16x2" = lc_conv2d_ring_wgrad_f16x2 (same split, same records; used
 # when the forward / dX convs are split too and the shape has whole 2 x 32 tiles), "f32" = exact fp32.
 TRAIN_WGRAD_PRECISION = os.environ.get("LC_TRAIN_WGRAD_PRECISION", "f16x2")
 
 
-# Attention of the training graph: "hip" = flash forward (f16x2 split, + log2-sum-exp) and exact-fp32 MFMA backward
-# (csrc/attention.hip, attention_bwd.hip: no score matrix in HBM, deterministic); "torch" = einsum / softmax over
-# materialised scores (the round-2/3 route; kept for A/B and for heads wider than 64 channels).
+# Attention of the training graph: "hip" = flash forward (+ log2-sum-exp) and flash backward that recomputes P, each in
+# the f16x2 split (default) or exact-fp32 MFMA (csrc/attention.hip, attention_bwd_h.hip, attention_bwd.hip: no score
+# matrix in HBM, deterministic); "torch" = einsum / softmax over materialised scores (the round-2/3 route; kept for
+# A/B and for heads wider than 64 channels).
 TRAIN_ATTENTION = os.environ.get("LC_TRAIN_ATTENTION", "hip")
 TRAIN_ATTN_FWD_PRECISION = os.environ.get("LC_TRAIN_ATTN_FWD_PRECISION", "f16x2")
 TRAIN_ATTN_BWD_PRECISION = os.environ.get("LC_TRAIN_ATTN_BWD_PRECISION", "f16x2")   # "f32": exact-fp32 MFMA backward
