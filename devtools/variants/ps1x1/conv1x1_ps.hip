@@ -27,12 +27,22 @@ namespace {
 #ifndef CAND_NBUF
 #define CAND_NBUF 2     // LDS chunk buffers: 2 = the next chunk lands under this chunk's MFMAs (measured 2-6 % ahead), 3 = prefetch distance of two chunks
 #endif
-constexpr int BN = 128, BP = 256, CBK = 4, NT = 512, NBUF = CAND_NBUF;
-constexpr int XS = CBK * BP, WS = CBK * BN;            // units per plane per buffer
-constexpr int BUF = 2 * XS + 2 * WS;                   // 48 KB per buffer (3 buffers: 144 KB of the CU's 160)
-constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk: 32 + 16
-constexpr int IPW = (NX + NW) / 8;                     // per wave: 6
+constexpr int CBK = 4, NBUF = CAND_NBUF;
 constexpr unsigned OOB = 0x80000000u;
+
+// block = WCO x WPX waves, each 64 output channels x 64 pixels
+template <int WCO_, int WPX_>
+struct Cfg {
+    static constexpr int WCO = WCO_, WPX = WPX_, NWV = WCO * WPX, NT = 64 * NWV;
+    static constexpr int BN = 64 * WCO, BP = 64 * WPX;
+    static constexpr int XS = CBK * BP, WS = CBK * BN;            // units per plane per buffer
+    static constexpr int BUF = 2 * XS + 2 * WS;
+    static constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk
+    static constexpr int IPW = (NX + NW) / NWV;                   // per wave
+    static constexpr int BLOCKS_PER_CU = (NBUF * BUF * 16 <= 80 * 1024 && NT <= 256) ? 2 : 1;
+    static_assert(NX % NWV == 0 && NW % NWV == 0, "slot kinds must not depend on the wave");
+    static_assert(NBUF * BUF * 16 <= 160 * 1024, "LDS");
+};
 
 struct P1Args {
     const half8* xsp; long long xsp_bs; int C8, P;
@@ -49,11 +59,14 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lds_vptr ds
 #endif
 }
 
-__global__ __launch_bounds__(NT, 1) void conv1x1_ps_kernel(P1Args a) {
+template <class C>
+__global__ __launch_bounds__(C::NT, C::BLOCKS_PER_CU) void conv1x1_ps_kernel(P1Args a) {
+    constexpr int BN = C::BN, BP = C::BP, XS = C::XS, WS = C::WS, BUF = C::BUF, NX = C::NX, NW = C::NW, IPW = C::IPW;
+    constexpr int NWV = C::NWV;
     __shared__ half8 lds[NBUF * BUF];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave >> 2, wpx = wave & 3;
+    const int wco = wave / C::WPX, wpx = wave % C::WPX;
     const int tiles_p = (a.P + BP - 1) / BP;
     const int b = blockIdx.x / tiles_p, p0 = (blockIdx.x - b * tiles_p) * BP;
     const int co0 = blockIdx.y * BN;
@@ -63,15 +76,14 @@ __global__ __launch_bounds__(NT, 1) void conv1x1_ps_kernel(P1Args a) {
     const unsigned wplane = (unsigned)a.Cib * (unsigned)a.Cop;                 // units per weight plane (1 tap)
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, 2u * wplane * 16u, 0x00020000);
 
-    // this wave's DMA instructions of a chunk: j = wave + 8 k; j < NX moves x, the rest weights
-    // (NX is a multiple of the 8 waves: the KIND of slot k is the same for every wave -- static, no branch in the issue code)
-    static_assert(NX % 8 == 0 && NW % 8 == 0, "slot kinds must not depend on the wave");
+    // this wave's DMA instructions of a chunk: j = wave + NWV k; j < NX moves x, the rest weights
+    // (NX is a multiple of the wave count: the KIND of slot k is the same for every wave -- static, no branch in the issue code)
     unsigned voff[IPW];
     int ldsoff[IPW];
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
-        const int j = wave + 8 * k;
-        if (j < NX) {
+        const int j = wave + NWV * k;
+        if (k < NX / NWV) {
             const int plane = j / (NX / 2), rem = j - plane * (NX / 2);
             const int cb = rem / (BP / 64), q = rem - cb * (BP / 64);
             const int p = p0 + q * 64 + lane;
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(NT, 1) void conv1x1_ps_kernel(P1Args a) {
     auto issue = [&](half8* buf, int ch) {
 #pragma unroll
         for (int k = 0; k < IPW; ++k)
-            if (k < NX / 8) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
+            if (k < NX / NWV) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
             else lds_dma16(rs_w, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * w_chunk);
     };
 
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(NT, 1) void conv1x1_ps_kernel(P1Args a) {
 extern "C" int cand_conv1x1_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias,
                                    const float* res, int64_t res_bs, float* y, int64_t y_bs, int B, int Ci, int Co,
                                    int P, float out_scale, const float* wmeta, const lc_conv_range* range,
-                                   void* stream) {
+                                   int cfg, void* stream) {
     if (!x_split || !wp_hi || !wp_lo || !y || !wmeta || !range || B <= 0 || Ci <= 0 || Co <= 0 || P <= 0) return -1;
     if (Ci % 32) return -2;
     if ((long long)2 * (Ci / 8) * P * 16 >= (1ll << 31)) return -2;
@@ -202,7 +214,17 @@ extern "C" int cand_conv1x1_ps_fwd(const void* x_split, const void* wp_hi, const
     if ((const half8*)wp_lo != a.wh + (long long)a.Cib * a.Cop) return -1;
     a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
     a.B = B; a.Co = Co; a.out_scale = out_scale; a.range = range; a.wmeta = wmeta;
-    dim3 grid((unsigned)(B * ((P + BP - 1) / BP)), (unsigned)((Co + BN - 1) / BN));
-    hipLaunchKernelGGL(conv1x1_ps_kernel, grid, dim3(NT), 0, (hipStream_t)stream, a);
+    auto launch = [&](auto cfg) {
+        using C = decltype(cfg);
+        dim3 grid((unsigned)(B * ((P + C::BP - 1) / C::BP)), (unsigned)((Co + C::BN - 1) / C::BN));
+        hipLaunchKernelGGL(conv1x1_ps_kernel<C>, grid, dim3(C::NT), 0, (hipStream_t)stream, a);
+    };
+    switch (cfg) {
+        case 0: launch(Cfg<2, 4>{}); break;      // 128 co x 256 px, 8 waves, 1 block per CU  (the first measurement)
+        case 1: launch(Cfg<2, 2>{}); break;      // 128 co x 128 px, 4 waves, 2 blocks per CU
+        case 2: launch(Cfg<4, 2>{}); break;      // 256 co x 128 px, 8 waves, 1 block per CU  (half the x re-reads)
+        case 3: launch(Cfg<1, 4>{}); break;      //  64 co x 256 px, 4 waves, 2 blocks per CU (the narrow projections)
+        default: return -2;
+    }
     return (int)hipGetLastError();
 }
