@@ -98,3 +98,18 @@ def test_weight_pack_job_record_layout():
     decls = [d.strip() for d in body.split(";") if d.strip()]
     assert decls == ["const float* w", "void *fwd_hi, *fwd_lo", "float* fwd_meta", "void *dx_hi, *dx_lo", "float* dx_meta",
                      "int Co, Ci, ks, reserved"], decls
+
+
+def test_prepare_model_leaves_a_cpu_model_alone():
+    """ops.prepare_model (called by inference.setup_model for a GPU model) packs nothing and loads nothing for weights
+    that are not on a GPU -- and there is still no CPU path behind it: the forward of such a model raises."""
+    import pytest
+
+    from lidarcrafter_amd import ops as K
+    from lidargen.models.unets import EfficientUNet
+
+    m = EfficientUNet(2, (8, 64), base_channels=16, coords_encoding="fourier_features", num_residual_blocks=(1, 1, 1, 1),
+                      gn_num_groups=8, gn_eps=1e-6, attn_num_heads=8, ring=True)
+    assert K.prepare_model(m) == 0
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 2, 8, 64), torch.zeros(1))
