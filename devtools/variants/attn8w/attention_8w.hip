@@ -1,0 +1,322 @@
+// CANDIDATE (not part of the product library; see README.md in this directory): the f16x2 flash attention forward with
+// 8 waves = 256 queries per block instead of 4 waves = 128.
+//
+// Why: attn_h_kernel is VALU-bound (profiles/r04_pmc_attn.txt: 14 VALU instructions per MFMA, matrix pipe busy 26 % of the
+// launch).  Of the ~250 VALU instructions a wave spends per 32-key tile, ~75 stage the K / V tile (global loads, the hi / lo
+// split, LDS writes) -- work that is per BLOCK, not per query.  With 256 queries per block the same staging serves twice
+// the queries, and it can be spread so that no wave does more than one split: waves 0-3 stage K (one unit per thread),
+// waves 4-5 stage V, waves 6-7 only compute.  Everything else is the shipped kernel (this file is a copy of its body from
+// lidarcrafter_amd/csrc/attention.hip with the NW template parameter added); results must be bit-identical to it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef struct lc_cm_operand { const float* p; int64_t bs, hs, cs; } lc_cm_operand;
+
+namespace {
+
+struct AttnArgs {
+    lc_cm_operand q, qp, k, kp, v, k2, k2p, v2;
+    float* o;
+    long long o_bs, o_hs, o_cs;
+    int heads, Lq, Lk0, Lk1, dqk, dpos, dv;
+    float qscale;  // scale * log2(e)
+    float* lse;
+};
+
+__device__ __forceinline__ const float* head_ptr(const lc_cm_operand& x, int b, int h) {
+    return x.p ? x.p + b * x.bs + h * x.hs : nullptr;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr float QK_PRE = 16.0f;      // q (after the softmax scale) and k are pre-scaled by 16
+constexpr float P_PRE = 2048.0f;     // p in [0,1]
+constexpr float P_LOG2 = 11.0f;      // log2(P_PRE)
+constexpr float V_PRE = 16.0f;
+
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& hi, half8& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const float s0 = scale == 1.0f ? v[k] : v[k] * scale;
+        const float s1 = scale == 1.0f ? v[k + 1] : v[k + 1] * scale;
+        const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+        const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+        const h2 ph = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+        f2 r; r.x = s0 - h0; r.y = s1 - h1;
+        const h2 pl = __builtin_convertvector(r, h2);
+        hi[k] = ph.x; hi[k + 1] = ph.y; lo[k] = pl.x; lo[k + 1] = pl.y;
+    }
+}
+
+template <int DQK, int NDV, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
+    constexpr int DV = NDV * 32;
+    constexpr int NKU = DQK / 8 * 32;    // K units [cb][key]
+    constexpr int NVU = 4 * DV;          // V units [step][half][c]
+    constexpr int NST = DQK / 16;        // k-steps of S^T
+    __shared__ half8 k_hi[NKU], k_lo[NKU], v_hi[NVU], v_lo[NVU];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = tid >> 6;
+    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
+    const int t = blockIdx.x * (32 * NW) + wave * 32 + l31;
+    const int Lk = a.Lk0 + a.Lk1;
+    const int dq = a.dqk + a.dpos;
+
+    half8 qh[NST], ql[NST];
+    {
+        const float* qc = head_ptr(a.q, b, h);
+        const float* qpos = head_ptr(a.qp, b, h);
+        const float qs = a.qscale * QK_PRE;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * st + 8 * kh + j;
+                float val = 0.f;
+                if (t < a.Lq) {
+                    if (c < a.dqk) val = qc[c * a.q.cs + t];
+                    else if (c < dq) val = qpos[(c - a.dqk) * a.qp.cs + t];
+                }
+                v[j] = val;
+            }
+            split8(v, qs, qh[st], ql[st]);
+        }
+    }
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int i = 0; i < NDV; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kc0 = head_ptr(a.k, b, h);
+    const float* kq0 = head_ptr(a.kp, b, h);
+    const float* vp0 = head_ptr(a.v, b, h);
+    const float* kc1 = head_ptr(a.k2, b, h);
+    const float* kq1 = head_ptr(a.k2p, b, h);
+    const float* vp1 = head_ptr(a.v2, b, h);
+
+    // staging roles: K unit (cb, key) for tid < NKU; V item (channel c, key octet o) for tid < NVU.
+    // dqk % 8 == 0 (checked by the launcher): the 8 channels of a K unit are all content or all
+    // positional, so each thread keeps ONE base pointer + channel stride per key segment and the
+    // K loop has no per-element address logic.  Threads without a role read a valid dummy
+    // address and store zeros.
+    static_assert(NW == 4 || (NKU <= 256 && NVU <= 128), "8 waves: K roles in waves 0-3, V roles in waves 4-5");
+    const int k_cb = tid >> 5, k_key = tid & 31;
+    const int vt = NW == 8 ? tid - 256 : tid;            // V roles: threads 256 ... 256 + NVU of an 8-wave block
+    const bool v_role = vt >= 0 && vt < NVU, k_role = tid < NKU;     // (both wave-uniform: NKU, NVU are multiples of 64)
+    const int v_c = (v_role ? vt : 0) >> 2, v_o = vt & 3;
+    const bool k_ok = k_role && k_cb * 8 < dq;
+    const bool v_ok = v_role && v_c < a.dv;
+    const float *kp0 = kc0, *kp1 = kc0, *vq0 = vp0, *vq1 = vp0;
+    long long kcs0 = 0, kcs1 = 0;
+    if (k_ok) {
+        const int c0 = k_cb * 8;
+        if (c0 < a.dqk) {
+            kp0 = kc0 + c0 * a.k.cs; kcs0 = a.k.cs;
+            if (a.Lk1 > 0) { kp1 = kc1 + c0 * a.k2.cs; kcs1 = a.k2.cs; }
+        } else {
+            kp0 = kq0 + (c0 - a.dqk) * a.kp.cs; kcs0 = a.kp.cs;
+            if (a.Lk1 > 0) { kp1 = kq1 + (c0 - a.dqk) * a.k2p.cs; kcs1 = a.k2p.cs; }
+        }
+        if (a.Lk1 == 0) { kp1 = kp0; kcs1 = kcs0; }
+    }
+    if (v_ok) {
+        vq0 = vp0 + v_c * a.v.cs;
+        vq1 = a.Lk1 > 0 ? vp1 + v_c * a.v2.cs : vq0;
+    }
+    // 16-byte loads of V are legal when every (channel row, key octet) start is 16-byte aligned
+    const bool v_vec = ((reinterpret_cast<uintptr_t>(vp0) & 15) == 0) && ((a.v.cs & 3) == 0);
+    float kreg[8], vreg[8];
+    auto load_tile = [&](int s0) {
+        if (NW == 8 && !k_role && !v_role) return;       // waves 6-7 of an 8-wave block stage nothing
+        if (s0 + 32 <= a.Lk0) {                 // whole tile inside segment 0 (uniform branch)
+            if (NW == 4 || k_role) {
+                const float* kp = kp0 + (s0 + k_key);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kreg[j] = kp[j * kcs0];
+            }
+            const float* vp = vq0 + (s0 + 8 * v_o);
+            if (NW == 8 && !v_role) {
+            } else if (v_vec) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(vp);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(vp + 4);
+                vreg[0] = x0.x; vreg[1] = x0.y; vreg[2] = x0.z; vreg[3] = x0.w;
+                vreg[4] = x1.x; vreg[5] = x1.y; vreg[6] = x1.z; vreg[7] = x1.w;
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) vreg[m] = vp[m];
+            }
+        } else {                                 // segment boundary and/or ragged end
+            {
+                const int s = s0 + k_key;
+                const bool in0 = s < a.Lk0, in1 = !in0 && s < Lk;
+                const float* kp = in0 ? kp0 + s : kp1 + (in1 ? s - a.Lk0 : 0);
+                const long long cs = in0 ? kcs0 : kcs1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float val = kp[j * cs];
+                    kreg[j] = (in0 || in1) ? val : 0.f;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int s = s0 + 8 * v_o + m;
+                const bool in0 = s < a.Lk0, in1 = !in0 && s < Lk;
+                const float val = in0 ? vq0[s] : vq1[in1 ? s - a.Lk0 : 0];
+                vreg[m] = (in0 || in1) ? val : 0.f;
+            }
+        }
+        if (!k_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kreg[j] = 0.f;
+        }
+        if (!v_ok) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) vreg[m] = 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+        if (tid < NKU) {
+            half8 hi, lo;
+            split8(kreg, QK_PRE, hi, lo);
+            k_hi[tid] = hi;                       // unit index = cb*32 + key = tid
+            k_lo[tid] = lo;
+        }
+        if (v_role) {
+            half8 hi, lo;
+            split8(vreg, V_PRE, hi, lo);
+            // keys 8o+0..3 -> (step o>>1, half 0), keys 8o+4..7 -> (step o>>1, half 1); both land
+            // in the 4-element piece (o&1) of their unit
+            const int u0 = ((v_o >> 1) * 2 + 0) * DV + v_c, u1 = u0 + DV;
+            half4* h0 = reinterpret_cast<half4*>(&v_hi[u0]) + (v_o & 1);
+            half4* h1 = reinterpret_cast<half4*>(&v_hi[u1]) + (v_o & 1);
+            half4* l0 = reinterpret_cast<half4*>(&v_lo[u0]) + (v_o & 1);
+            half4* l1 = reinterpret_cast<half4*>(&v_lo[u1]) + (v_o & 1);
+            *h0 = __builtin_shufflevector(hi, hi, 0, 1, 2, 3);
+            *h1 = __builtin_shufflevector(hi, hi, 4, 5, 6, 7);
+            *l0 = __builtin_shufflevector(lo, lo, 0, 1, 2, 3);
+            *l1 = __builtin_shufflevector(lo, lo, 4, 5, 6, 7);
+        }
+    };
+
+    constexpr float S_UN = 1.0f / (QK_PRE * QK_PRE);
+    load_tile(0);
+    for (int s0 = 0; s0 < Lk; s0 += 32) {
+        __syncthreads();   // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (s0 + 32 < Lk) load_tile(s0 + 32);   // in flight while this tile is computed
+        // ---- S^T = K^T Q (scaled by QK_PRE^2) -------------------------------------------------
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const half8 ah = k_hi[(2 * st + kh) * 32 + l31];
+            const half8 al = k_lo[(2 * st + kh) * 32 + l31];
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[st], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[st], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[st], sacc, 0, 0, 0);
+        }
+        // ---- online softmax (base 2) ------------------------------------------------------------
+        if (s0 + 32 > Lk) {    // ragged last tile (uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = s0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (key >= Lk) sacc[r] = -INFINITY;
+            }
+        }
+        float mt = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * S_UN;
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // p' = P_PRE * 2^(s - m): the pre-scale of the split is folded into the exponent, the
+        // running sum carries the same factor and it cancels in the final division
+        const float m_off = P_LOG2 - m_new;
+        float psum = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], S_UN, m_off));
+            psum += p[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // uniform: some lane's max moved
+#pragma unroll
+            for (int i = 0; i < NDV; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
+        // ---- O^T += V P^T (scaled by P_PRE * V_PRE) -----------------------------------------------
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = p[8 * st + j];
+            half8 ph, pl;
+            split8(pv, 1.0f, ph, pl);
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                const half8 avh = v_hi[(st * 2 + kh) * DV + i * 32 + l31];
+                const half8 avl = v_lo[(st * 2 + kh) * DV + i * 32 + l31];
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, ph, oacc[i], 0, 0, 0);
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, pl, oacc[i], 0, 0, 0);
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, ph, oacc[i], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / (l_tot * V_PRE);
+    float* op = a.o + b * a.o_bs + h * a.o_hs;
+    if (a.lse && t < a.Lq && kh == 0) a.lse[(long long)bh * a.Lq + t] = m_run + log2f(l_tot) - P_LOG2;   // (l_run carries P_PRE)
+    if (t < a.Lq) {
+#pragma unroll
+        for (int i = 0; i < NDV; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (c < a.dv) op[c * a.o_cs + t] = oacc[i][r] * inv;
+            }
+    }
+}
+
+}  // namespace
+
+// The argument list of lc_attention_f16x2_fwd plus `waves` (4 = the shipped block, 8 = the candidate); d_qk + d_pos <= 64, d_v <= 32
+extern "C" int cand_attention_f16x2_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos, const lc_cm_operand* k,
+                                        const lc_cm_operand* k_pos, const lc_cm_operand* v, const lc_cm_operand* k2,
+                                        const lc_cm_operand* k2_pos, const lc_cm_operand* v2, float* o, int64_t o_bs,
+                                        int64_t o_hs, int64_t o_cs, int B, int heads, int Lq, int Lk0, int Lk1, int dqk,
+                                        int dpos, int dv, float scale, int waves, void* stream) {
+    if (!q || !k || !v || !o || dqk % 8 || dqk + dpos > 64 || dv > 32 || (waves != 4 && waves != 8)) return -1;
+    const lc_cm_operand none = {nullptr, 0, 0, 0};
+    AttnArgs a;
+    a.q = *q; a.qp = q_pos ? *q_pos : none; a.k = *k; a.kp = k_pos ? *k_pos : none; a.v = *v;
+    a.k2 = k2 ? *k2 : none; a.k2p = k2_pos ? *k2_pos : none; a.v2 = v2 ? *v2 : none;
+    a.o = o; a.o_bs = o_bs; a.o_hs = o_hs; a.o_cs = o_cs;
+    a.heads = heads; a.Lq = Lq; a.Lk0 = Lk0; a.Lk1 = Lk1; a.dqk = dqk; a.dpos = dpos; a.dv = dv;
+    a.qscale = scale * 1.4426950408889634f;
+    a.lse = nullptr;
+    const int qpb = 32 * waves;
+    dim3 grid((Lq + qpb - 1) / qpb, B * heads);
+    const bool d32 = dqk + dpos <= 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (waves == 4) {
+        if (d32) hipLaunchKernelGGL((attn_h_kernel<32, 1, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_h_kernel<64, 1, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        if (d32) hipLaunchKernelGGL((attn_h_kernel<32, 1, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_h_kernel<64, 1, 8>), grid, dim3(512), 0, st, a);
+    }
+    return (int)hipGetLastError();
+}
