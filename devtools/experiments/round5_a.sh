@@ -5,3 +5,5 @@
 mkdir -p gpurun_out/r05a
 timeout 120 python devtools/variants/ps1x1/run.py 8 0 1 2 3 2>&1 | grep -E "^8:|Error|error|assert" | tee gpurun_out/r05a/ps1x1.txt
 timeout 120 python devtools/variants/attn8w/run.py 2>&1 | grep -E "heads|Error|error|assert" | tee gpurun_out/r05a/attn8w.txt
+# Also waiting, each a `git merge` away (compiled, never run): branch cfg26-8x32 (8 x 32 level-0 tile: then
+#   python devtools/conv_time.py 8:64:64:32:1024 --gn --res --emit --cfg 26   against --cfg 0, and pytest -k "test_conv")
