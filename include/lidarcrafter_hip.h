@@ -187,7 +187,7 @@ int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, in
  * already multiplied by the CONSUMER layer's x_scale (`range`, whose amax_scaled it maintains: the
  * range-safety contract of lc_conv_range moves to the producer).  lc_conv2d_ring_f16x2_ps_fwd then
  * stages its tiles with LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPRs, no VALU, no ds_write in
- * the K loop.  3x3 ring convolution, pipelined tile shapes (tile_cfg 0 = auto, 12/13/15/22/23/25/28);
+ * the K loop.  3x3 ring convolution, pipelined tile shapes (tile_cfg 0 = auto, 12/13/15/22/23/25/26/28);
  * wp_lo must be wp_hi + one plane (ONE allocation holding both planes of
  * lc_pack_conv_weight_f16x2).  Everything else as lc_conv2d_ring_f16x2_fwd. */
 int64_t lc_split_act_units(int B, int C, int H, int W);

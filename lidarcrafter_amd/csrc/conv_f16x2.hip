@@ -1751,6 +1751,7 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
         case 22: return launch_pipe<HCfg<1, 8, 2, 1, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px
         case 23: return launch_pipe<HCfg<2, 4, 1, 2, 4, 64, KS>>(a, st);  // 8 waves, 64 co x 256 px (1x2)
         case 25: return launch_pipe<HCfg<2, 4, 1, 1, 2, 64, KS>>(a, st);  // 8 waves, 64 co x 128 px
+        case 26: return launch_pipe<HCfg<2, 4, 1, 2, 8, 32, KS>>(a, st);  // 8 waves, 64 co x (8 rows x 32 px): halo 1.33x instead of 1.55x
         case 28: return launch_pipe<HCfg<1, 8, 1, 1, 4, 64, KS>>(a, st);  // 8 waves, 32 co x 256 px (Co <= 32)
         case 33: return KS == 3 ? launch_pp(a, st) : LC_EUNSUP;           // ping-pong wave groups, 64 co x 256 px
         default: return LC_EUNSUP;
@@ -1768,6 +1769,7 @@ int pipe_stat_slots(int cfg, int H, int W) {
         case 22: th = 4; tw = 64; wpx = 8; break;
         case 23: th = 4; tw = 64; wpx = 4; break;
         case 25: th = 2; tw = 64; wpx = 4; break;
+        case 26: th = 8; tw = 32; wpx = 4; break;
         case 28: th = 4; tw = 64; wpx = 8; break;
         case 33: th = 4; tw = 64; wpx = 4; break;
         default: return 0;

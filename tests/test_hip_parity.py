@@ -32,7 +32,7 @@ def dev():
     (2, 64, 96, 1, 2048, 1), (1, 32, 64, 1, 192, 1),
     (2, 96, 64, 4, 64, 1), (1, 192, 64, 8, 64, 1),      # 1x1 with a partial last 64-channel chunk
 ])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 223, 423, 425, 412, 212, 28, 228, 33])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 26, 226, 223, 423, 425, 412, 212, 28, 228, 33])
 @pytest.mark.parametrize("prec", ["f32", "f16x2"])
 def test_conv(dev, B, Ci, Co, H, W, ks, cfg, prec):
     from lidarcrafter_amd import ops as K
@@ -72,7 +72,7 @@ def test_conv_f16x2_accuracy_vs_fp64(dev):
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks,G", [(2, 64, 64, 8, 128, 3, 8), (1, 256, 128, 8, 256, 3, 32),
                                               (2, 48, 32, 4, 64, 3, 8), (2, 512, 96, 4, 128, 1, 32),
                                               (1, 128, 64, 32, 1024, 3, 8)])
-@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25, 423, 225])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25, 26, 423, 225])
 def test_conv_fused_groupnorm(dev, B, Ci, Co, H, W, ks, G, cfg):
     """GN(+AdaGN scale/shift)+SiLU applied inside the conv staging == GN kernel then conv."""
     from lidarcrafter_amd import ops as K
