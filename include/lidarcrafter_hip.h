@@ -206,6 +206,14 @@ int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const vo
                                 int tile_cfg, float* gn_ostats_out,
                                 float* splitk_part /* NULL, or [ksplit, B, Co, H, W] */, int ksplit,
                                 const float* wmeta, lc_conv_range* range, lc_stream_t s);
+/* 1x1 convolution of a pre-split activation (the same planes; H * W is one pixel axis): LDS-DMA staging, 128 output
+ * channels x 256 pixels per block -- for projections with many output channels, where the fp32-input kernel splits the
+ * same input tile once per 64-channel block (qkv projections of the layout model).  Needs Ci % 32 == 0 (LC_EUNSUP
+ * otherwise); weights: the ks = 1 pack, lo plane directly behind the hi plane; no statistics output, no split-K. */
+int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias,
+                            const float* res, int64_t res_bs, float* y, int64_t y_bs, int B, int Ci, int Co,
+                            int H, int W, float out_scale, const float* wmeta, lc_conv_range* range,
+                            lc_stream_t s);
 /* SPLIT-K for small grids (batch 1-2 at the deep levels: 16-64 blocks on 256 CUs): with splitk_part
  * != NULL the conv launches ksplit (2 ... Ci/16) blocks per tile, each over a contiguous range of
  * the K chunks, and stores raw partial sums only (bias / res / out_scale / statistics are ignored);

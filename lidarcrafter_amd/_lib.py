@@ -62,6 +62,7 @@ SIGNATURES = {
                                        f32, i32, vp, vp]),
     "lc_groupnorm_apply_os_split": (i32, [vp, i64, _os, _os, vp, vp, vp, vp, i64, vp, i32, i32, i32,
                                           i32, i32, f32, i32, vp, vp]),
+    "lc_conv1x1_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lc_conv2d_ring_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32,
                                           f32, i32, vp, vp, i32, vp, vp, vp]),
     "lc_range_from_tensor": (i32, [vp, i64, i32, i64, vp, vp]),
@@ -167,7 +168,7 @@ def lib_p1() -> C.CDLL:
         if not os.path.exists(path):
             raise HipLibraryMissing(f"{path} not found: run `python -m lidarcrafter_amd.build`")
         handle = C.CDLL(path)
-        for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd"):
+        for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd", "lc_conv1x1_f16x2_ps_fwd"):
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = SIGNATURES[name]
         _lib_p1 = handle

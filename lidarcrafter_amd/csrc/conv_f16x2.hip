@@ -2161,6 +2161,8 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
     return dispatch_h<3>(tile_cfg, a, lc_s(s));
 }
 
+#include "conv_f16x2_ps1.h"
+
 // ---- split-K finish ------------------------------------------------------------------------------
 namespace {
 // y = (sum_z part[z] + bias [+ res]) * out_scale, one thread per (pixel, channel octet): the ksplit

@@ -1,0 +1,193 @@
+// 1x1 convolution of a PRE-SPLIT activation (included by conv_f16x2.hip behind the pre-split 3x3 kernel).
+//
+// A 1x1 conv has no tap reuse: on conv_f16x2_kernel<KS = 1> every 64-channel output block stages and SPLITS the same fp32
+// input tile again (the qkv projections of the layout model have 12 / 24 such blocks per pixel tile: 57 us per launch,
+// 1.03 ms of the 9.05 ms C3 step in round 4).  When the GroupNorm in front writes fp16 hi / lo planes anyway
+// (lc_groupnorm_apply*_split: xsp[b][plane][c/8][p][8], pre-multiplied by the layer's x_scale), this kernel consumes
+// them with LDS-DMA only -- no VALU in the K loop:
+//
+//   block  = 8 waves, 128 output channels x 256 pixels (no spatial structure: pixels = the H*W plane)
+//   wave   = 64 channels x 64 pixels (2 x 2 accumulators of 32 x 32), waves 2 (channels) x 4 (pixels)
+//   chunk  = 32 input channels (4 units of 8): 2 k-steps x 12 MFMAs per wave between two barriers, two LDS buffers of
+//            48 KB (x: 2 planes x 4 x 256 units, w: 2 planes x 4 x 128 units), 48 DMA wave-instructions per chunk
+//
+// Same arithmetic as every f16x2 kernel: wh*xh + wh*xl + wl*xh in fp32, * 1 / (x_scale * w_scale), + bias (+ res),
+// * out_scale.  Needs Ci % 32 == 0.  First measurement (devtools/variants/ps1x1/README.md): GroupNorm + projection
+// 256 -> 768 @ 8 x 256, batch 8: 74.9 -> 54.4 us; 512 -> 1536 @ 4 x 128: 64.8 -> 39.9 us.
+#pragma once
+
+namespace {
+
+struct P1 {
+    static constexpr int BN = 128, BP = 256, CBK = 4, NT = 512;
+    static constexpr int XS = CBK * BP, WS = CBK * BN;            // units per plane per buffer
+    static constexpr int BUF = 2 * XS + 2 * WS;                   // 48 KB
+    static constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk: 32 + 16
+    static constexpr int IPW = (NX + NW) / 8;                     // per wave: 6
+    static_assert(NX % 8 == 0 && NW % 8 == 0, "the kind of a DMA slot must not depend on the wave");
+};
+
+struct P1Args {
+    const half8* xsp; long long xsp_bs; int C8, P;
+    const half8* wh; int Cib, Cop;
+    const float* bias; const float* res; long long res_bs;
+    float* y; long long y_bs;
+    int Co; float out_scale;
+    const lc_conv_range* range; const float* wmeta;
+};
+
+__global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
+    constexpr int BN = P1::BN, BP = P1::BP, CBK = P1::CBK, XS = P1::XS, WS = P1::WS, BUF = P1::BUF;
+    constexpr int NX = P1::NX, NW = P1::NW, IPW = P1::IPW;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ half8 lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 2, wpx = wave & 3;
+    const int tiles_p = (a.P + BP - 1) / BP;
+    const int b = blockIdx.x / tiles_p, p0 = (blockIdx.x - b * tiles_p) * BP;
+    const int co0 = blockIdx.y * BN;
+
+    const unsigned xbytes = 2u * (unsigned)a.C8 * (unsigned)a.P * 16u;
+    __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.xsp + (long long)b * a.xsp_bs), 0, xbytes, 0x00020000);
+    const unsigned wplane = (unsigned)a.Cib * (unsigned)a.Cop;                 // units per weight plane (one tap)
+    __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, 2u * wplane * 16u, 0x00020000);
+
+    // this wave's DMA instructions of a chunk: j = wave + 8 k; slots k < NX / 8 move x, the rest weights (static kinds)
+    unsigned voff[IPW];
+    int ldsoff[IPW];
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+        const int j = wave + 8 * k;
+        if (k < NX / 8) {
+            const int plane = j / (NX / 2), rem = j - plane * (NX / 2);
+            const int cb = rem / (BP / 64), q = rem - cb * (BP / 64);
+            const int p = p0 + q * 64 + lane;
+            ldsoff[k] = plane * XS + cb * BP + q * 64;
+            voff[k] = p < a.P ? (unsigned)((plane * a.C8 + cb) * a.P + p) * 16u : OOB;
+        } else {
+            const int jw = j - NX;
+            const int plane = jw / (NW / 2), rem = jw - plane * (NW / 2);
+            const int cb = rem / (BN / 64), q = rem - cb * (BN / 64);
+            const int cu = co0 + q * 64 + lane;
+            ldsoff[k] = 2 * XS + plane * WS + cb * BN + q * 64;
+            voff[k] = cu < a.Cop ? ((unsigned)(cb * a.Cop + cu) + plane * wplane) * 16u : OOB;
+        }
+    }
+    const unsigned x_chunk = (unsigned)CBK * (unsigned)a.P * 16u;      // bytes between K chunks (x)
+    const unsigned w_chunk = (unsigned)CBK * (unsigned)a.Cop * 16u;    // ... (weights)
+    auto issue = [&](half8* buf, int ch) {
+#pragma unroll
+        for (int k = 0; k < IPW; ++k)
+            if (k < NX / 8) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
+            else lds_dma16(rs_w, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * w_chunk);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nchunk = a.C8 / CBK;
+    half8* cur = lds;
+    half8* nxt = lds + BUF;
+    issue(cur, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) issue(nxt, ch + 1);          // lands while this chunk's MFMAs run
+        const half8* xh = cur;
+        const half8* xl = cur + XS;
+        const half8* wh = cur + 2 * XS;
+        const half8* wl = wh + WS;
+#pragma unroll
+        for (int ks = 0; ks < CBK / 2; ++ks) {
+            half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = wh[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
+                al[i] = wl[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = xh[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
+                bl[j] = xl[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        half8* t = cur; cur = nxt; nxt = t;
+    }
+
+    // ---- epilogue: accumulator register r of a lane = channel (r & 3) + 8 (r >> 2) + 4 kh of the 32, pixel l31 ----------
+    const float out_unscale = a.range->x_unscale * a.wmeta[1];
+    float* yb = a.y + (long long)b * a.y_bs;
+    const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    const int co_lane = co0 + wco * 64 + 4 * kh;
+    float bias_r[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
+            bias_r[i][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = p0 + wpx * 64 + j * 32 + l31;
+        const bool pok = p < a.P;
+        float res_r[2][16];                                 // all residual loads of this pixel column in flight together
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
+                res_r[i][r] = (rb && pok && co < a.Co) ? rb[(long long)co * a.P + p] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (pok && co < a.Co)
+                    epi_store(&yb[(long long)co * a.P + p],
+                              ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][r]) * a.out_scale);
+            }
+    }
+}
+
+}  // namespace
+
+// x_split: [B][2][Ci/8][P][8] halves as lc_groupnorm_apply*_split write them (P = H * W); wp_hi / wp_lo / wmeta: the ks = 1
+// pack of lc_pack_conv_weight_f16x2 (lo plane directly behind the hi plane); y, res: fp32 [B][Co][P] with batch strides.
+extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias,
+                                       const float* res, int64_t res_bs, float* y, int64_t y_bs, int B, int Ci,
+                                       int Co, int H, int W, float out_scale, const float* wmeta,
+                                       lc_conv_range* range, lc_stream_t s) {
+    if (!x_split || !wp_hi || !wp_lo || !y || !wmeta || !range || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0)
+        return LC_EINVAL;
+    if (Ci % 32) return LC_EUNSUP;
+    const long long P = (long long)H * W;
+    if (P >= (1 << 24) || 2 * (Ci / 8) * P * 16 >= (1ll << 31) || (long long)Co * P * 4 >= (1ll << 31)) return LC_EUNSUP;
+    P1Args a;
+    a.xsp = (const half8*)x_split; a.C8 = Ci / 8; a.P = (int)P; a.xsp_bs = 2ll * (Ci / 8) * P;
+    a.wh = (const half8*)wp_hi; a.Cib = Ci / 8; a.Cop = (Co + 63) / 64 * 64;
+    if ((const half8*)wp_lo != a.wh + (long long)a.Cib * a.Cop) return LC_EINVAL;    // one allocation, lo behind hi
+    a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
+    a.Co = Co; a.out_scale = out_scale; a.range = range; a.wmeta = wmeta;
+    dim3 grid((unsigned)(B * ((P + P1::BP - 1) / P1::BP)), (unsigned)((Co + P1::BN - 1) / P1::BN));
+    hipLaunchKernelGGL(conv1x1_ps_kernel, grid, dim3(P1::NT), 0, lc_s(s), a);
+    return lc_launch_status();
+}

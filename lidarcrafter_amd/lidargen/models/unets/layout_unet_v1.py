@@ -203,7 +203,10 @@ class ObjectAwareCrossAttention(nn.Module):
         else:
             xs = x.contiguous().view(B, C, L1)
         pos_img, pos_lay, k_lay, v_lay, per_sample = self.condition_operands(cond_kwargs)
-        if K.fuse_gn(3 * C):
+        if K.presplit_1x1(C, 3 * C, self.norm_for_qkv.num_groups):
+            # many output channels: the norm writes hi / lo planes once, the projection stages them by LDS-DMA
+            qkv = self.qkv_projector(self.norm_for_qkv(xs, split_for=self.qkv_projector._packed))
+        elif K.fuse_gn(3 * C):
             qkv = self.qkv_projector(xs, gn_coeffs=gn32_coeffs(self.norm_for_qkv, xs))
         else:
             qkv = self.qkv_projector(self.norm_for_qkv(xs))

@@ -27,6 +27,9 @@ class GroupNorm32(nn.GroupNorm):
         if x.dim() == 4 and split_for is not None and out is None:
             return K.groupnorm(x, self.num_groups, self.eps, self.weight, self.bias, scale, shift,
                                act_silu=act_silu, split_for=split_for)
+        if x.dim() == 3 and split_for is not None and out is None:      # tokens for a pre-split 1x1 projection
+            return K.groupnorm(_tok4(x), self.num_groups, self.eps, self.weight, self.bias, scale, shift,
+                               act_silu=act_silu, split_for=split_for)
         if x.dim() == 3:
             B, C, L = x.shape
             o4 = None if out is None else out.view(B, C, 1, L)
@@ -61,9 +64,13 @@ class PointwiseConv1d(nn.Conv1d):
         self._packed = K.PackedConv()
 
     def forward(self, x, res=None, out=None, gn_coeffs=None, gn_silu=False, emit_stats=False):
-        B, C, L = x.shape
         r4 = None if res is None else _tok4(res)
         o4 = None if out is None else _tok4(out)
+        if isinstance(x, K.SplitAct):                  # [B, C, 1, L] tokens written pre-split for THIS layer
+            B, _, _, L = x.shape
+            y = K.conv2d_ring(x, self._packed, self.weight, self.bias, res=r4, out=o4)
+            return K.alias(y.view(B, -1, L), y)
+        B, C, L = x.shape
         y = K.conv2d_ring(_tok4(x), self._packed, self.weight, self.bias, res=r4,
                           out=o4, gn_coeffs=gn_coeffs, gn_silu=gn_silu, emit_stats=emit_stats)
         return K.alias(y.view(B, -1, L), y)

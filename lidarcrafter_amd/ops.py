@@ -607,6 +607,17 @@ def can_presplit(C: int, G: int) -> bool:
     return PRESPLIT and CONV_PRECISION == "f16x2" and C % 16 == 0 and G > 0 and C % G == 0
 
 
+# 1x1 projections with many output channels take a pre-split input too (lc_conv1x1_f16x2_ps_fwd): the fp32-input 1x1
+# kernel splits the same input tile once per 64-channel output block.  Measured ahead from 512 output channels
+# (devtools/variants/ps1x1/README.md); LC_PS1X1_MIN_CO=0 turns the route off.
+PS1X1_MIN_CO = int(_os.environ.get("LC_PS1X1_MIN_CO", "512"))
+
+
+def presplit_1x1(Ci: int, Co: int, G: int) -> bool:
+    """Should the GroupNorm in front of a Ci -> Co 1x1 projection write the pre-split form for it?"""
+    return PS1X1_MIN_CO > 0 and Co >= PS1X1_MIN_CO and Ci % 32 == 0 and can_presplit(Ci, G)
+
+
 class PackedConv:
     """Packed copies of an OIHW conv weight for the MFMA kernels (fp32 wp[tap][Ci^8][Co^64] and/or
     the f16x2 hi/lo planes + their device-derived pre-scale), rebuilt when the parameter changes;
@@ -975,8 +986,8 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                          "(its x_scale belongs to that layer's range record)")
     wh, wl = packed.get_f16x2(weight)
     B, Ci, H, W = xs.shape
-    if Ci != packed.Ci or packed.ks != 3:
-        raise ValueError("conv: pre-split input needs a 3x3 kernel with matching channels")
+    if Ci != packed.Ci or packed.ks not in (1, 3):
+        raise ValueError("conv: pre-split input needs a 1x1 / 3x3 kernel with matching channels")
     Co = packed.Co
     dev = xs.buf.device
     if out is None:
@@ -992,6 +1003,13 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
     if bias is not None:
         _req(bias, "bias")
     _drop_stats(out)
+    if packed.ks == 1:                       # (no statistics output: a consumer GroupNorm takes its own pass)
+        with _Timed("conv1x1", 2.0 * B * H * W * Co * Ci):
+            check(_conv_lib().lc_conv1x1_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), _p(res),
+                                                      r_bs, out.data_ptr(), y_bs, B, Ci, Co, H, W, float(out_scale),
+                                                      packed.wmeta.data_ptr(), packed.range_ptr(dev), _stream()),
+                  "lc_conv1x1_f16x2_ps_fwd")
+        return out
     ks = splitk_factor(B, Ci, Co, H, W) if tile_cfg == 0 else 0
     with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9):
         sbuf, slots = None, 0

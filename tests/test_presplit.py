@@ -167,3 +167,33 @@ def test_conv_presplit_split_k(dev, B, Ci, Co, H, W):
     if Co % 64 == 0:
         assert K._find_stats(y, 8) is not None
         assert rel_l2(K.groupnorm(y, 8, 1e-6), K.groupnorm(y.clone(), 8, 1e-6)) < 2e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,with_res", [(8, 256, 768, 8, 256, False), (2, 512, 1536, 4, 128, False),
+                                                  (2, 256, 256, 1, 2048, True), (3, 64, 96, 5, 50, True),
+                                                  (1, 128, 640, 1, 37, False)])
+def test_conv1x1_presplit_matches_fp32_route(dev, B, Ci, Co, H, W, with_res):
+    """GroupNorm32 -> 1x1 projection with the activation handed over pre-split (lc_conv1x1_f16x2_ps_fwd) vs the fp32
+    hand-over and float64: ragged pixel counts, output-channel tails, token shapes (H = 1), residual + scale."""
+    from lidarcrafter_amd import ops as K
+
+    x = (seeded_randn(B, Ci, H, W, seed=1) * 2 + 0.3).to(dev)
+    w = (seeded_randn(Co, Ci, 1, 1, seed=2) / Ci ** 0.5).to(dev)
+    b = seeded_randn(Co, seed=3).to(dev)
+    res = seeded_randn(B, Co, H, W, seed=4).to(dev) if with_res else None
+    gam, bet = (seeded_randn(Ci, seed=5) * 0.2 + 1).to(dev), (seeded_randn(Ci, seed=6) * 0.1).to(dev)
+    pk0, pk1 = K.PackedConv("fp32-in"), K.PackedConv("presplit-in")
+    y0 = K.conv2d_ring(K.groupnorm(x, 32, 1e-5, gam, bet), pk0, w, b, res=res, out_scale=0.5)
+    sa = K.groupnorm(x, 32, 1e-5, gam, bet, split_for=pk1)
+    assert isinstance(sa, K.SplitAct)
+    y1 = K.conv2d_ring(sa, pk1, w, b, res=res, out_scale=0.5)
+    assert not K.range_poll(dev)
+    ref = torch.nn.functional.conv2d(
+        torch.nn.functional.group_norm(x.double(), 32, gam.double(), bet.double(), 1e-5), w.double(), b.double())
+    ref = ((ref + res.double()) if with_res else ref) * 0.5
+    assert rel_l2(y1, ref) < 2e-6, rel_l2(y1, ref)
+    assert rel_l2(y1, y0) < 2e-6
+    # into a caller's strided output (a slice of a wider buffer), as the modules pass `out=`
+    wide = torch.zeros(B, Co + 8, H, W, device=dev)
+    K.conv2d_ring(K.groupnorm(x, 32, 1e-5, gam, bet, split_for=pk1), pk1, w, b, res=res, out=wide[:, 4:4 + Co], out_scale=0.5)
+    assert torch.equal(wide[:, 4:4 + Co], y1) and float(wide[:, :4].abs().max()) == 0.0
