@@ -12,7 +12,7 @@ for t in 1 3 5; do
 done
 wait
 for t in 1 3 5; do
-  objs=$(ls $OBJ/*.o | grep -v conv_f16x2.o)
+  objs=$(ls $OBJ/*.o | grep -v conv_f16x2)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o devtools/variants/liblc_terms$t.so \
       $objs devtools/variants/conv_f16x2_t$t.o
 done

@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "liblidarcrafter_hip.so")
 # the convolution kernels alone with ONE fp16 product per multiply (-DLC_F16X2_TERMS=1): what a caller under
 # torch.autocast(float16) asked for (the reference's bulk harness); never used otherwise (ops.conv_products)
 LIB_P1 = os.path.join(HERE, "liblidarcrafter_hip_p1.so")
-SOURCES = ["conv.hip", "conv_f16x2.hip", "norm.hip", "resample.hip", "misc.hip", "attention.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip", "conv_bwd.hip", "attention_bwd.hip", "attention_bwd_h.hip"]
+SOURCES = ["conv.hip", "conv_f16x2.hip", "conv_f16x2_tall.hip", "norm.hip", "resample.hip", "misc.hip", "attention.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip", "conv_bwd.hip", "attention_bwd.hip", "attention_bwd_h.hip"]
 
 
 def hipcc() -> str:
@@ -45,10 +45,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
                os.path.join(CSRC, src), "-o", obj] + os.environ.get("LC_EXTRA_HIPCC_FLAGS", "").split()
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
-    p1_obj = os.path.join(HERE, "build", "conv_f16x2_p1.o")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DLC_F16X2_TERMS=1", "-c",
-           os.path.join(CSRC, "conv_f16x2.hip"), "-o", p1_obj] + os.environ.get("LC_EXTRA_HIPCC_FLAGS", "").split()
-    procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    p1_objs = []
+    for src in ("conv_f16x2.hip", "conv_f16x2_tall.hip"):
+        p1_obj = os.path.join(HERE, "build", src.replace(".hip", "_p1.o"))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DLC_F16X2_TERMS=1", "-c",
+               os.path.join(CSRC, src), "-o", p1_obj] + os.environ.get("LC_EXTRA_HIPCC_FLAGS", "").split()
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        p1_objs.append(p1_obj)
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -57,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(out.decode())
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
-    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_P1, p1_obj], check=True)
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_P1] + p1_objs, check=True)
     if verbose:
         print("built", LIB, "and", os.path.basename(LIB_P1))
     return LIB

@@ -32,7 +32,7 @@ def dev():
     (2, 64, 96, 1, 2048, 1), (1, 32, 64, 1, 192, 1),
     (2, 96, 64, 4, 64, 1), (1, 192, 64, 8, 64, 1),      # 1x1 with a partial last 64-channel chunk
 ])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 26, 226, 223, 423, 425, 412, 212, 28, 228, 33])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 12, 13, 15, 22, 23, 25, 27, 227, 427, 223, 423, 425, 412, 212, 28, 228, 33])
 @pytest.mark.parametrize("prec", ["f32", "f16x2"])
 def test_conv(dev, B, Ci, Co, H, W, ks, cfg, prec):
     from lidarcrafter_amd import ops as K
@@ -72,7 +72,7 @@ def test_conv_f16x2_accuracy_vs_fp64(dev):
 @pytest.mark.parametrize("B,Ci,Co,H,W,ks,G", [(2, 64, 64, 8, 128, 3, 8), (1, 256, 128, 8, 256, 3, 32),
                                               (2, 48, 32, 4, 64, 3, 8), (2, 512, 96, 4, 128, 1, 32),
                                               (1, 128, 64, 32, 1024, 3, 8)])
-@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25, 26, 423, 225])
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 12, 13, 23, 25, 27, 227, 423, 225])
 def test_conv_fused_groupnorm(dev, B, Ci, Co, H, W, ks, G, cfg):
     """GN(+AdaGN scale/shift)+SiLU applied inside the conv staging == GN kernel then conv."""
     from lidarcrafter_amd import ops as K
@@ -339,9 +339,11 @@ def test_epilogue_statistics_entries_under_load(dev, unit):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,ns", [(2, 64, 64, 8, 128, 1), (1, 64, 64, 32, 256, 2), (1, 128, 64, 16, 128, 2),
                                              (2, 64, 128, 16, 64, 1), (1, 192, 64, 8, 64, 1), (1, 64, 64, 32, 128, 4),
-                                             (1, 64, 64, 12, 64, 3), (8, 64, 64, 32, 1024, 0)])
-@pytest.mark.parametrize("mode", ["plain", "gn_silu_res_oct", "gn_res_pairs", "adagn_two_segments"])
-def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode):
+                                             (1, 64, 64, 12, 64, 3), (8, 64, 64, 32, 1024, 0), (1, 64, 64, 32, 64, 8),
+                                             (2, 32, 64, 16, 128, 2), (1, 32, 96, 8, 64, 0), (1, 128, 64, 32, 64, 0)])
+@pytest.mark.parametrize("mode", ["plain", "gn_silu_res_oct", "gn_res_pairs", "gn_oct_nores", "adagn_two_segments"])
+@pytest.mark.parametrize("kern", [33, 27])
+def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode, kern):
     """The ping-pong kernel (tile cfg 33, conv_f16x2_pp.h) against the oracle and -- bit for bit -- against the
     pipelined kernel (cfg 23) on the same inputs: plain input, fused GroupNorm(+SiLU) from a statistics pass, from a
     producer's octet entries and from the pair entries of two concatenated producers, with bias / residual / output
@@ -349,7 +351,14 @@ def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode):
     from lidarcrafter_amd import ops as K
     from oracle import denoiser as D
 
-    cfg = 33 + 100 * ns
+    if kern == 33 and (Ci < 64 or Co % 64):
+        pytest.skip("outside the ping-pong kernel's shapes")
+    if kern == 33 and mode == "gn_oct_nores":
+        pytest.skip("covered by the other modes")
+    # tile cfg 27 = the tall kernel (conv_f16x2_tall.hip: kept halo rows, transposed accumulators, 16-byte epilogue);
+    # shapes / modes it does not take (Ci not 32 or 64, pair entries) run on the pipelined kernel by its launcher's
+    # fallback -- same statistics partition either way
+    cfg = kern + 100 * ns
     x = (seeded_randn(B, Ci, H, W, seed=401) * 1.3 + 0.4).to(dev)
     w = (seeded_randn(Co, Ci, 3, 3, seed=402) / (Ci * 9) ** 0.5).to(dev)
     bias = seeded_randn(Co, seed=403).to(dev)
@@ -367,6 +376,11 @@ def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode):
         ref = (D.conv_ring(D.silu(D.group_norm(x.cpu(), 8, ga.cpu(), be.cpu(), 1e-6)), w.cpu(), bias.cpu())
                + res.cpu()) * 0.7071 if small else None
         emit = True
+    elif mode == "gn_oct_nores":
+        kw = dict(bias=bias, gn_silu=False, out_scale=1.25)
+        gn = lambda: K.groupnorm_stats(x, 8, 1e-6, ga, be)
+        ref = D.conv_ring(D.group_norm(x.cpu(), 8, ga.cpu(), be.cpu(), 1e-6), w.cpu(), bias.cpu()) * 1.25 if small else None
+        emit = True
     elif mode == "gn_res_pairs":
         kw = dict(res=res, gn_silu=False)
         gn = lambda: K.groupnorm_stats(x, 32, 1e-6, ga, be)
@@ -374,8 +388,8 @@ def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode):
         emit = 2
     else:
         # the input is a concat of two producers that left statistics (octet entries; different tile shapes)
-        if Ci % 128:
-            pytest.skip("two 64-channel producers")
+        if Ci % 64:
+            pytest.skip("two producers of Ci / 2 channels, 8 channels per group")
         src = seeded_randn(B, 32, H, W, seed=408).to(dev)
         w1 = (seeded_randn(Ci // 2, 32, 3, 3, seed=409) / 17.0).to(dev)
         w2 = (seeded_randn(Ci // 2, 32, 3, 3, seed=410) / 11.0).to(dev)
@@ -383,10 +397,11 @@ def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode):
         K.conv2d_ring(src, K.PackedConv(), w1, bias[:1].repeat(Ci // 2), out=x[:, :Ci // 2], tile_cfg=23, emit_stats=True)
         K.conv2d_ring(src, K.PackedConv(), w2, None, out=x[:, Ci // 2:], tile_cfg=13, emit_stats=True)
         kw = dict(bias=bias, gn_silu=True)
-        gn = lambda: K.groupnorm_stats(x, 16, 1e-6, ga, be, ss[:, :Ci], ss[:, Ci:])
+        G2 = Ci // 8
+        gn = lambda: K.groupnorm_stats(x, G2, 1e-6, ga, be, ss[:, :Ci], ss[:, Ci:])
         assert gn()._struct.partials is None
         xc = x.cpu()
-        a = D.silu(D.group_norm(xc, 16, ga.cpu(), be.cpu(), 1e-6) * (1 + ss.cpu()[:, :Ci, None, None])
+        a = D.silu(D.group_norm(xc, G2, ga.cpu(), be.cpu(), 1e-6) * (1 + ss.cpu()[:, :Ci, None, None])
                    + ss.cpu()[:, Ci:, None, None])
         ref = D.conv_ring(a, w.cpu(), bias.cpu()) if small else None
         emit = True
@@ -398,7 +413,10 @@ def test_conv_pp_matches_pipe(dev, B, Ci, Co, H, W, ns, mode):
     y = outs[cfg]
     if ref is not None:
         assert rel_l2(y, ref) < 3e-6, rel_l2(y, ref)
-    assert torch.equal(y, outs[23]), rel_l2(y, outs[23])
+    if kern == 33:
+        assert torch.equal(y, outs[23]), rel_l2(y, outs[23])
+    else:   # the transposed MFMA sums the same products in the same order per K step; the epilogue's fma matches too
+        assert rel_l2(y, outs[23]) < 5e-7, rel_l2(y, outs[23])
     if emit:
         unit = 8 if emit is True else 2
         h = y._lc_gnstats[(0, Co)]
