@@ -139,7 +139,8 @@ def measure_hbm_traffic(timeout_s: int = 150):
                 if row["Counter_Name"] != counter:
                     continue
                 k = row["Kernel_Name"]
-                if "conv_f16x2" in k and ("Li3EEEE" in k or ", 3>" in k):   # the 3x3 instantiations
+                # the 3x3 instantiations (HCfg<..., 3>) and the tall level-0 kernel (3x3 only)
+                if "conv_f16x2" in k and ("Li3EEEE" in k or ", 3>" in k or "tall_kernel" in k):
                     tot += float(row["Counter_Value"]) * 1024.0
                     n += 1
             if n == 0:
@@ -311,12 +312,14 @@ def main():
         torch.cuda.synchronize()
         rec, K.PROFILE = K.PROFILE, None
         fam = {}
-        for name, work, e0, e1 in rec:
-            a = fam.setdefault(name, [0.0, 0.0, 0])
+        for name, work, e0, e1, rd, wr in rec:
+            a = fam.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
             a[0] += work
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
-        w, t, n = fam["conv3x3"]
+            a[3] += rd
+            a[4] += wr
+        w, t, n, alg_rd, alg_wr = fam["conv3x3"]
         achieved = w / t / 1e12
         split = K.CONV_PRECISION == "f16x2"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
@@ -342,12 +345,17 @@ def main():
                     break
             tdetail = None
         roof = {"bound": "mfma",
-                "kernel": ("conv_f16x2_kernel<KS=3>" if split else "conv_ring_kernel<KS=3>") +
+                "kernel": ("conv_f16x2_{tall,pipe,ps}_kernel<KS=3>" if split else "conv_ring_kernel<KS=3>") +
                           " (all tile instantiations)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": tsource, "traffic_detail": tdetail,
-                "algorithmic_bytes_per_launch": round(70.0e6) if BATCH_PER_GPU == 8 else None,
+                # from the layer shapes of the launches themselves: input + packed weights + residual (where the layer
+                # reads one) read once, output written once
+                "algorithmic_bytes_per_launch": round((alg_rd + alg_wr) / n),
+                "algorithmic_read_bytes_per_launch": round(alg_rd / n),
+                "algorithmic_write_bytes_per_launch": round(alg_wr / n),
+                "traffic_read_write": (tdetail if isinstance(tdetail, dict) else None),
                 "note": ("achieved counts ALGORITHMIC flops (2*MACs); the f16x2 split issues 3 "
                          "f16 MFMAs per product, so the attainable ceiling of this kernel is "
                          "peak/3 = 833 TFLOP/s" if split else
@@ -395,6 +403,8 @@ def main():
                        "graph_setup_steps": setup,
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world,
                        "resolution": list(RES), "parallelism": f"dp{world} (no data-path collective)",
+                       "collectives": ("rccl: barrier + all_reduce(MAX) + all_gather of the frames executed" if dist_on
+                                       else "none (single process: no process group)"),
                        "rng": "x_T from per-sample CPU generators (global sample index); the timed DDIM steps run with "
                               "rng=None (eta = 0 uses no noise).  The parity mode -- a CPU generator per sample, "
                               "advanced every step as the reference does -- is timed as a row of its own: "

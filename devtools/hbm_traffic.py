@@ -15,7 +15,7 @@ def fold(path, counter):
             continue
         v = float(r["Counter_Value"]) * 1024.0
         allk += v
-        if "conv_f16x2" in r["Kernel_Name"] and ("Li3EEEE" in r["Kernel_Name"] or ", 3>" in r["Kernel_Name"]):
+        if "conv_f16x2" in r["Kernel_Name"] and ("Li3EEEE" in r["Kernel_Name"] or ", 3>" in r["Kernel_Name"] or "tall_kernel" in r["Kernel_Name"]):
             tot += v
             n += 1
     return tot, n, allk

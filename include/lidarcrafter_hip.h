@@ -38,7 +38,9 @@ int lc_abi_version(void);
 /* Writes gcnArchName of the current device into buf (NUL terminated). */
 int lc_device_arch(char* buf, int buflen);
 /* Loads the code objects of every translation unit of the library for the CURRENT device now (HIP defers that to a
- * unit's first kernel launch, i.e. into the first sampling step of a process).  Idempotent, no device work. */
+ * unit's first kernel launch, i.e. into the first sampling step of a process).  Idempotent, no device work.
+ * Returns LC_OK or -- like every launcher of this header when the HIP runtime refuses a launch -- the POSITIVE hipError_t
+ * of the failing runtime call (LC_E* codes are negative); callers treat it as a warm-up that did not happen. */
 int lc_load_code_objects(void);
 
 /* ---------------------------------------------------------------------------------------------

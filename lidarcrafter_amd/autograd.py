@@ -61,11 +61,11 @@ def training_active(module: torch.nn.Module, *tensors) -> bool:
     """True when the caller expects an autograd graph: grad mode on and something requires grad."""
     if not torch.is_grad_enabled():
         return False
-    active = any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors) or \
+    # (a pure predicate: the "this forward took the training graph" mark of ops.range_checked is set where the graph
+    #  is ENTERED -- begin_training_forward -- not here: a caller that merely asks, e.g. `training_active(...) and
+    #  hasattr(...)`, must not switch the fp16 saturation check off for a forward that runs the inference kernels)
+    return any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors) or \
         any(p.requires_grad for p in module.parameters())
-    if active:
-        K._range_defer.autograd_route = True      # tells ops.range_checked that this forward needs no poll
-    return active
 
 
 # max|.| left behind by the pass that WROTE a tensor (GroupNormAct forward / backward: one partial maximum per block, plain
@@ -80,7 +80,10 @@ MULTI_WEIGHT_PACK = os.environ.get("LC_TRAIN_MULTI_WEIGHT_PACK", "1") != "0"
 
 
 def begin_training_forward(device) -> None:
-    """Start of a forward through the training graph: weights that an optimizer step moved are packed now, all at once."""
+    """Start of a forward through the training graph: weights that an optimizer step moved are packed now, all at once.
+    Marks the forward for ops.range_checked: every operand's pre-scale is measured on the device right before its conv
+    (range_from_tensor / producer maxima), so the post-forward poll and retry of the inference path are skipped."""
+    K._range_defer.autograd_route = True
     if MULTI_WEIGHT_PACK and TRAIN_CONV_PRECISION == "f16x2":
         K.train_weight_plan(device).refresh()
 

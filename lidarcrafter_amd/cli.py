@@ -42,10 +42,15 @@ def main(argv=None):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
+    # under torchrun (RANK / WORLD_SIZE exported) the process group is created for ONE rank too: the same RCCL
+    # init / all-gather path runs on a single-GPU box as on the 8-GPU node (tests/test_rccl_single_gpu.py)
+    dist_on = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and args.device == "cuda")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = torch.device(args.device, torch.cuda.current_device()) if args.device == "cuda" \
         else torch.device(args.device)
 
@@ -80,7 +85,7 @@ def main(argv=None):
         torch.save(out.cpu(), os.path.join(args.out, "samples.pt"))
         print(f"{args.cfg}: {out.shape[0]} frames, {args.sampling_steps} {args.mode} steps, "
               f"{dt:.2f} s ({args.sampling_steps / dt:.1f} denoising-steps/s) -> {args.out}/samples.pt")
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

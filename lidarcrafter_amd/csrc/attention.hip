@@ -14,6 +14,8 @@
 //   -> B is register r of the S^T accumulator as is: k-step r contracts keys
 //      kappa(r,half) = (r&3)+8*(r>>2)+4*half, and V is read from LDS with the same kappa.
 // Block = 4 waves x 32 queries of one head; K/V tiles of 32 keys staged in LDS.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -196,8 +198,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& 
     }
 }
 
-template <int DQK, int NDV>
-__global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
+// NW = waves per block (32 queries each).  4: the block of rounds 1-4.  8 (round 5): the K / V staging of a tile is
+// per-BLOCK work (~75 of the ~250 VALU instructions a wave spends per 32-key tile, profiles/r04_pmc_attn.txt); 256
+// queries per block halve it per query, and the roles are dealt so that no wave splits more than one operand: waves
+// 0-3 stage K, waves 4-5 stage V, waves 6-7 only compute.  Bit-identical results; 2048 + 13 keys 241.8 -> 227.4 us,
+// 512 + 13 keys 45.6 -> 40.0, 512 keys 29.1 -> 25.0 (profiles/r05_level0.txt section 1).
+template <int DQK, int NDV, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
     constexpr int DV = NDV * 32;
     constexpr int NKU = DQK / 8 * 32;    // K units [cb][key]
     constexpr int NVU = 4 * DV;          // V units [step][half][c]
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = tid >> 6;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
-    const int t = blockIdx.x * 128 + wave * 32 + l31;
+    const int t = blockIdx.x * (32 * NW) + wave * 32 + l31;
     const int Lk = a.Lk0 + a.Lk1;
     const int dq = a.dqk + a.dpos;
 
@@ -250,10 +257,13 @@ __global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
     // positional, so each thread keeps ONE base pointer + channel stride per key segment and the
     // K loop has no per-element address logic.  Threads without a role read a valid dummy
     // address and store zeros.
+    static_assert(NW == 4 || (NW == 8 && NKU <= 256 && NVU <= 128), "8 waves: K roles in waves 0-3, V roles in waves 4-5");
     const int k_cb = tid >> 5, k_key = tid & 31;
-    const int v_c = tid >> 2, v_o = tid & 3;
-    const bool k_ok = tid < NKU && k_cb * 8 < dq;
-    const bool v_ok = tid < NVU && v_c < a.dv;
+    const int vt = NW == 8 ? tid - 256 : tid;            // V roles: threads 256 ... 256 + NVU of an 8-wave block
+    const bool v_role = vt >= 0 && vt < NVU, k_role = tid < NKU;     // (both wave-uniform: NKU, NVU are multiples of 64)
+    const int v_c = (v_role ? vt : 0) >> 2, v_o = vt & 3;
+    const bool k_ok = k_role && k_cb * 8 < dq;
+    const bool v_ok = v_role && v_c < a.dv;
     const float *kp0 = kc0, *kp1 = kc0, *vq0 = vp0, *vq1 = vp0;
     long long kcs0 = 0, kcs1 = 0;
     if (k_ok) {
@@ -275,12 +285,16 @@ __global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
     const bool v_vec = ((reinterpret_cast<uintptr_t>(vp0) & 15) == 0) && ((a.v.cs & 3) == 0);
     float kreg[8], vreg[8];
     auto load_tile = [&](int s0) {
+        if (NW == 8 && !k_role && !v_role) return;       // waves 6-7 of an 8-wave block stage nothing
         if (s0 + 32 <= a.Lk0) {                 // whole tile inside segment 0 (uniform branch)
-            const float* kp = kp0 + (s0 + k_key);
+            if (NW == 4 || k_role) {
+                const float* kp = kp0 + (s0 + k_key);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kreg[j] = kp[j * kcs0];
+                for (int j = 0; j < 8; ++j) kreg[j] = kp[j * kcs0];
+            }
             const float* vp = vq0 + (s0 + 8 * v_o);
-            if (v_vec) {
+            if (NW == 8 && !v_role) {
+            } else if (v_vec) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(vp);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(vp + 4);
                 vreg[0] = x0.x; vreg[1] = x0.y; vreg[2] = x0.z; vreg[3] = x0.w;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(256) void attn_h_kernel(AttnArgs a) {
             k_hi[tid] = hi;                       // unit index = cb*32 + key = tid
             k_lo[tid] = lo;
         }
-        if (tid < NVU) {
+        if (v_role) {
             half8 hi, lo;
             split8(vreg, V_PRE, hi, lo);
             // keys 8o+0..3 -> (step o>>1, half 0), keys 8o+4..7 -> (step o>>1, half 1); both land
@@ -453,6 +467,16 @@ static int attention_launch(int split, float* lse, const lc_cm_operand* q, const
     dim3 grid((Lq + 127) / 128, B * heads);
     const int dq = (dqk + dpos) <= 32 ? 32 : 64, nd = dv <= 32 ? 1 : 2;
     if (split && dqk % 8 == 0) {   // (a K unit = 8 channels of ONE operand; else the fp32 kernel)
+        // 256 queries per block (8 waves) where d_v <= 32 and the grid still covers the chip (measured: every such layer
+        // of the layout model and the 512-key self-attention gain 6-14 %; a 300-token batch-2 case loses 12 %)
+        static const int w8_env = [] { const char* e = getenv("LC_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+        const long long blocks8 = (long long)((Lq + 255) / 256) * B * heads;
+        if (nd == 1 && (w8_env == 8 || (w8_env == 0 && blocks8 >= 128))) {
+            dim3 grid8((Lq + 255) / 256, B * heads);
+            if (dq == 32) hipLaunchKernelGGL((attn_h_kernel<32, 1, 8>), grid8, dim3(512), 0, lc_s(s), a);
+            else hipLaunchKernelGGL((attn_h_kernel<64, 1, 8>), grid8, dim3(512), 0, lc_s(s), a);
+            return lc_launch_status();
+        }
         if (dq == 32 && nd == 1) hipLaunchKernelGGL((attn_h_kernel<32, 1>), grid, dim3(256), 0, lc_s(s), a);
         else if (dq == 64 && nd == 1) hipLaunchKernelGGL((attn_h_kernel<64, 1>), grid, dim3(256), 0, lc_s(s), a);
         else if (dq == 32 && nd == 2) hipLaunchKernelGGL((attn_h_kernel<32, 2>), grid, dim3(256), 0, lc_s(s), a);

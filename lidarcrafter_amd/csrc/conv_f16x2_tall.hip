@@ -47,6 +47,14 @@ using namespace lcconv;
 #ifndef LC_TALL_DMA_ASM
 #define LC_TALL_DMA_ASM 1 // weight LDS-DMA through inline assembly (see dma_w)
 #endif
+#ifndef LC_TALL_PRIO
+#define LC_TALL_PRIO 0    // static wave priority for the K loop: 1 = s_setprio 1 for the younger half (waves 4-7), 2 = for the older half
+#endif
+#ifndef LC_TALL_T0
+#define LC_TALL_T0 3      // taps that stage pixel 0 / pixel 1 / the edge element of the next chunk (the rows are read one tap before T0)
+#define LC_TALL_T1 5
+#define LC_TALL_T2 7
+#endif
 #ifndef LC_TALL_AHEAD
 #define LC_TALL_AHEAD 2   // x loads run this many K chunks ahead of the chunk that stages them (1 or 2)
 #endif
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
 #pragma unroll
         for (int tap = 0; tap < NTAP; ++tap) {
             const int s = tap & 1;
-            if (tap == 2) { stage_rows(xst, NC); __builtin_amdgcn_sched_barrier(0); }   // rows ahead of the fragment fetch (no lgkmcnt(0))
+            if (tap == LC_TALL_T0 - 1) { stage_rows(xst, NC); __builtin_amdgcn_sched_barrier(0); }   // rows ahead of the fragment fetch (no lgkmcnt(0))
             if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             if (!(LC_TALL_ABL & 8) && C * NTAP + tap < DE::NUSED) de.slot(C * NTAP + tap);
@@ -419,9 +427,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
             // exactly the later taps' deferred operations in flight (a reordering by hipcc only makes it stricter)
             if (tap < KW && !(LC_TALL_ABL & 16)) dma_w(wnext, tap, NC);
             if (AH == 2 && tap == KW) load_x(xl, LC);
-            if (tap == 3) stage_px(xst, 0, dreg_b);
-            if (tap == 5) stage_px(xst, 1, dreg_b);
-            if (tap == 7) stage_edge(xst, NC, dreg_b);
+            if (tap == LC_TALL_T0) stage_px(xst, 0, dreg_b);
+            if (tap == LC_TALL_T1) stage_px(xst, 1, dreg_b);
+            if (tap == LC_TALL_T2) stage_edge(xst, NC, dreg_b);
             if (LC_TALL_ABL & 4) {
                 asm volatile("" ::"v"(wh_[s]), "v"(wl_[s]), "v"(xh_[s][0]), "v"(xl_[s][0]), "v"(xh_[s][1]), "v"(xl_[s][1]));
                 __builtin_amdgcn_sched_barrier(0);
@@ -460,6 +468,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the prologue's weight DMA has landed
     __syncthreads();
+    if (LC_TALL_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (LC_TALL_PRIO == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
     LC_TT(t_pro)
     for (int t = 0; t < NTL; ++t) {
         k_iter(std::integral_constant<int, 0>{}, t);

@@ -84,6 +84,7 @@ class PointUNet(nn.Module):
         cond = cond_dict["other_condition"].reshape(B, -1).float()
         cond_emb = torch.cat([beta, torch.sin(beta), torch.cos(beta), cond], dim=-1).contiguous()
         if AG.training_active(self, coords, cond):
+            K._range_defer.autograd_route = True     # torch ops only below: no f16x2 operand to poll
             # training (tools/train/train_object.py): six point-wise dense layers -- plain
             # differentiable torch ops on the device (rocBLAS), the reference's own arithmetic order
             ce = cond_emb[:, None, :]

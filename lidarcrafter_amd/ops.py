@@ -93,15 +93,16 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 # Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg sets
-# PROFILE to a list; entries are (kernel_family, algorithmic_work, start_event, end_event)).
+# PROFILE to a list; entries are (kernel_family, algorithmic_work, start_event, end_event, bytes_read, bytes_written)).
 PROFILE = None
 
 
 class _Timed:
-    __slots__ = ("name", "work", "e0")
+    __slots__ = ("name", "work", "e0", "rd", "wr")
 
-    def __init__(self, name, work):
-        self.name, self.work, self.e0 = name, work, None
+    def __init__(self, name, work, rd=0.0, wr=0.0):
+        # rd / wr: algorithmic bytes the launch must read / write once (inputs + packed weights + residual; output)
+        self.name, self.work, self.e0, self.rd, self.wr = name, work, None, rd, wr
 
     def __enter__(self):
         if PROFILE is not None:
@@ -113,7 +114,7 @@ class _Timed:
         if self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.append((self.name, self.work, self.e0, e1))
+            PROFILE.append((self.name, self.work, self.e0, e1, self.rd, self.wr))
         return False
 
 
@@ -193,8 +194,11 @@ def set_conv_precision(mode: str) -> str:
 # tensor drops the statistics of what it overwrites.
 # Default ON again since round 4.  (End of round 3 it was switched off: the entry was ONE 128-bit buffer store with
 # an SGPR soffset, and ~3 entries in 10^7 arrived with a foreign upper dword under the store pressure of the deferred
-# epilogue.  The entry is now four 32-bit stores; devtools/entry_stress.py recomputes every entry of 10^8 per entry
-# unit: 0 off, against 17 in 5e7 for the old form on the same box -- profiles/r04_entry_store.txt.)
+# epilogue.  The entry is now ONE 32-bit store instruction in which the four lanes below the reducing lane carry one field
+# each (DefEpi::store_entry_lanes: the sum reaches lane R-1 by a DPP row_shl, pivot and count are uniform over lanes
+# R-3 .. R); devtools/entry_stress.py recomputes every entry of 10^8 per entry unit: 0 off, against 17 in 5e7 for the
+# old form on the same box -- profiles/r04_entry_store.txt.  Regression guard in the GPU suite:
+# tests/test_hip_parity.py::test_conv_statistics_entries_stress.)
 # LC_GN_PRODUCER_STATS=0 selects the statistics-pass route (one lc_groupnorm_stats launch per GroupNorm).
 PRODUCER_GN_STATS = _os.environ.get("LC_GN_PRODUCER_STATS", "1") != "0"
 
@@ -347,7 +351,7 @@ import threading as _threading
 
 class _Defer(_threading.local):
     depth = 0
-    autograd_route = False      # set by autograd.training_active when a forward takes the training graph
+    autograd_route = False      # set by autograd.begin_training_forward when a forward ENTERS the training graph
 
 
 _range_defer = _Defer()          # per thread: a sampler thread's deferral does not silence another's
@@ -565,8 +569,8 @@ def range_checked(forward):
             _range_defer.autograd_route = False
             out = forward(self, *args, **kw)
             if _range_defer.autograd_route:
-                # the forward took the training graph (autograd.training_active said so AND the forward acted on
-                # it): every operand's pre-scale was measured on the device right before its conv
+                # the forward took the training graph (autograd.begin_training_forward ran): every operand's
+                # pre-scale was measured on the device right before its conv
                 # (range_from_tensor), nothing can be invalid -- and a poll would be a blocking device->host copy per
                 # step, a retry a second graph with new dropout masks.  A grad-mode call that ran the INFERENCE
                 # kernels (precomputed time_features) is polled like any other.
@@ -755,7 +759,13 @@ class TrainWeightPlan:
     instead of ~5 per layer: every layer registers (forward weight, its forward and input-gradient PackedConv) the first
     time it runs; from the next step on `refresh()` -- called at the start of a training forward -- notices that weights
     moved on, packs all of them into per-layer buffers that stay put, and primes the PackedConv caches, so the
-    per-layer `get_f16x2` / `get_f16x2_dx` calls of that step find their packs valid."""
+    per-layer `get_f16x2` / `get_f16x2_dx` calls of that step find their packs valid.
+
+    "Moved on" is read from the tensors' autograd VERSION COUNTERS (what optimizer steps, `copy_`, `load_state_dict` and
+    every in-place op on the parameter bump).  An update that bypasses the counter -- in-place arithmetic on `p.data`,
+    a raw-pointer write -- is invisible to it: call `invalidate()` (or `ops.train_weight_plan(dev).invalidate()`) after
+    such an update, otherwise the forward / input-gradient packs stay stale while the weight gradient reads the live
+    weights."""
 
     def __init__(self, device):
         self.device = device
@@ -784,6 +794,11 @@ class TrainWeightPlan:
             shape=(Co, Ci, ks, ks), ptr=base.data_ptr(), fh=buf[:nf], fl=buf[nf:2 * nf], dh=buf[2 * nf:2 * nf + nd],
             dl=buf[2 * nf + nd:], fmeta=meta[:4], dmeta=meta[4:], buf=buf, meta=meta, packed_version=None)
         self.table = None
+
+    def invalidate(self) -> None:
+        """Forget every pack's version: the next refresh() packs all registered weights again."""
+        for e in self.entries.values():
+            e["packed_version"] = None
 
     def refresh(self) -> int:
         """Pack every registered weight if any of them changed since its last pack; returns the number packed."""
@@ -856,8 +871,16 @@ def prepare_model(module: torch.nn.Module) -> int:
                     pk.get(w)
             n += 1
     if dev is not None:
+        # best effort: this only moves the code-object loads out of the first sampling step.  A failure here (a positive
+        # return is the hipError_t of hipFuncGetAttributes, e.g. on a device the library was not built for) must not
+        # abort model setup with a code that points at the warm-up -- the first real launch reports the real problem.
         with torch.cuda.device(dev):
-            check(lib().lc_load_code_objects(), "lc_load_code_objects")
+            rc = int(lib().lc_load_code_objects())
+        if rc != 0:
+            import warnings
+
+            warnings.warn(f"lc_load_code_objects: hipError {rc} while pre-loading the kernels' code objects; continuing "
+                          "(they load at their first launch)")
     return n
 
 
@@ -941,7 +964,9 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
         _req(bias, "bias")
     ks = packed.ks
     _drop_stats(out)
-    with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks):
+    with _Timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * B * H * W * Co * Ci * ks * ks,
+                rd=4.0 * (B * Ci * H * W + Co * Ci * ks * ks + (B * Co * H * W if res is not None else 0)),
+                wr=4.0 * B * Co * H * W):
         if prec == "f16x2":
             cpad = 0
             gs_ref = None
@@ -1011,7 +1036,9 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                   "lc_conv1x1_f16x2_ps_fwd")
         return out
     ks = splitk_factor(B, Ci, Co, H, W) if tile_cfg == 0 else 0
-    with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9):
+    with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9,     # (pre-split x: 2 fp16 planes = 4 bytes per element too)
+                rd=4.0 * (B * Ci * H * W + Co * Ci * 9 + (B * Co * H * W if res is not None else 0)),
+                wr=4.0 * B * Co * H * W):
         sbuf, slots = None, 0
         # (pair entries -- emit_stats == 2 -- come from the fp32-input kernel's deferred epilogue only)
         want_stats = emit_stats and (emit_stats is True or int(emit_stats) == 8) and PRODUCER_GN_STATS and \
@@ -1420,7 +1447,10 @@ def add_scale(a: torch.Tensor, b: torch.Tensor, scale: float, out=None) -> torch
 PROJECTION_DTYPE = _os.environ.get("LC_PROJECTION_DTYPE", "native")
 
 
-_proj_ws = {}
+import threading as _threading
+
+_proj_ws = {}          # (device, stream, H * W, thread) -> self-emptying z-buffer
+_PROJ_WS_MAX = 16
 
 
 def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down: float,
@@ -1453,14 +1483,21 @@ def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down
     dev = points.device
     # z-buffer: one per (device, stream, H * W), emptied once; every projection hands it back empty
     # (lc_project_points_ws): two launches and no scratch allocation per call
+    # The cached buffer is shared state: it is keyed by the calling THREAD as well (two host threads on one stream would
+    # otherwise interleave scatter A, scatter B, gather A, gather B on it), never used while the stream is being
+    # captured (a replayed graph would race with eager calls on the same buffer: a capture gets a private one, owned by
+    # the graph's pool), and the cache holds at most _PROJ_WS_MAX entries (streams come and go; oldest evicted).
     st = _stream()
-    key = (dev, st, H * W)
-    zbuf = _proj_ws.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev, st, H * W, _threading.get_ident())
+    zbuf = None if capturing else _proj_ws.get(key)
     if zbuf is None:
         with torch.inference_mode(False):
             zbuf = torch.empty(H * W, device=dev, dtype=torch.int64)
         check(lib().lc_project_workspace_init(zbuf.data_ptr(), H * W, st), "lc_project_workspace_init")
-        if not torch.cuda.is_current_stream_capturing():   # (memory allocated during a capture belongs to that graph's pool)
+        if not capturing:
+            while len(_proj_ws) >= _PROJ_WS_MAX:
+                _proj_ws.pop(next(iter(_proj_ws)))
             _proj_ws[key] = zbuf
     img = torch.empty((H, W, 6), device=dev, dtype=_F32)
     win = torch.empty((H, W), device=dev, dtype=torch.int32)

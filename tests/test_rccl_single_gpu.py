@@ -1,0 +1,65 @@
+"""The collective path on hardware, with the one GPU the test box has: RCCL process group (`nccl` backend with
+`device_id`), barrier, `all_reduce(MAX)` of the timing and the all-gather of the generated frames on DEVICE tensors --
+what `bench.py --gpus N` and `python -m lidarcrafter_amd.cli` under torchrun execute on the 8-GPU node, here with
+world size 1 (the reference's per-rank loop: tools/evaluation/sample_and_save_cond.py:33-38,157-159).
+The world-size-2 logic (shard ranges, padded all-gather, shard-invariant frames) is covered on CPU by
+tests/test_parallel_gloo.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update({k: str(v) for k, v in kw.items()})
+    return env
+
+
+def test_bench_takes_the_rccl_path_with_one_rank():
+    assert torch.cuda.is_available()
+    env = _env(LC_BENCH_FORCE_DIST=1, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
+                        "--repeat", "1", "--no-cpu-baseline", "--no-traffic"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 2 and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("dp1")
+    assert d["verify"]["ok"] is True                     # the 50-step check against the reference fixture ran inside it
+    assert d["config"].get("collectives") == "rccl: barrier + all_reduce(MAX) + all_gather of the frames executed"
+
+
+def test_cli_under_torchrun_one_rank(tmp_path):
+    assert torch.cuda.is_available()
+    out = tmp_path / "samples"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "lidarcrafter_amd.cli", "--cfg", "nuscenes-unet-uncond",
+           "--batch_size", "2", "--sampling_steps", "3", "--out", str(out)]
+    p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+    frames = torch.load(out / "samples.pt")
+    assert frames.shape == (2, 5, 32, 1024) and torch.isfinite(frames).all()
+    # the same frames without a process group (shard-invariance, world 1): bit-equal
+    out2 = tmp_path / "plain"
+    p2 = subprocess.run([sys.executable, "-m", "lidarcrafter_amd.cli", "--cfg", "nuscenes-unet-uncond", "--batch_size", "2",
+                         "--sampling_steps", "3", "--out", str(out2)], env=_env(), cwd=ROOT, capture_output=True, text=True,
+                        timeout=600)
+    assert p2.returncode == 0, (p2.stdout + p2.stderr)[-2000:]
+    assert torch.equal(frames, torch.load(out2 / "samples.pt"))
