@@ -4,6 +4,6 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p devtools/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c lidarcrafter_amd/csrc/conv_f16x2.hip -o devtools/variants/conv_$1.o 2>/dev/null
-objs=$(ls lidarcrafter_amd/build/*.o | grep -v conv_f16x2)
+objs=$(ls lidarcrafter_amd/build/*.o | grep -v "conv_f16x2\.o\|_p1\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o devtools/variants/liblc_$1.so $objs devtools/variants/conv_$1.o
 echo built devtools/variants/liblc_$1.so

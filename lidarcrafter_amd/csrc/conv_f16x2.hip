@@ -745,7 +745,10 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
     // range and lands in a 1 KiB dummy block behind the buffer.
     constexpr int KX = (2 * NXI + NWV - 1) / NWV, KW = (2 * NWI + NWV - 1) / NWV;
     constexpr int IPW = KX + KW;
-    constexpr int SPT = (IPW + NTAP - 1) / NTAP;                  // slots issued per tap (1 with 8 waves)
+#ifndef LC_PS_SPT
+#define LC_PS_SPT 0   // developer switch: DMA slots issued per tap (0 = spread over all taps: 1 with 8 waves)
+#endif
+    constexpr int SPT = LC_PS_SPT ? LC_PS_SPT : (IPW + NTAP - 1) / NTAP;   // slots issued per tap
     constexpr int BUF = 2 * XS + 2 * WS + 64;                     // + the dummy block
     constexpr unsigned OOB = 0x80000000u;
     __shared__ half8 lds[2 * BUF];

@@ -390,11 +390,34 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     __shared__ double sh[12];
     const int oct = blockIdx.y, b = blockIdx.z;
     const int c0 = oct * 8, cpg = C / G, g = c0 / cpg;
+    // The first 8 x 16-byte loads of this thread go out BEFORE the statistics fold (round 5): they do not depend on
+    // it, and the fold (entry loads, fp64 shuffles, one barrier: ~1.5 us) otherwise sits in front of every block's
+    // first HBM access -- 30 launches of this kernel per C2 step.
+    const float* xp = x + b * x_bs + (long long)c0 * HW;
+    const long long per = (HW + gridDim.x - 1) / gridDim.x;
+    const long long lo = blockIdx.x * per;
+    const long long hi = lo + per < HW ? lo + per : HW;
+    const bool vec = (HW & 3) == 0 && (per & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0;
+    f32x4 c4_first[8];
+    auto issue_first = [&]() {      // (behind the fold's own entry loads: VMEM returns in order, the fold must not wait for x)
+        asm volatile("" ::: "memory");
+        // unconditional loads (a predicated load is an exec-mask branch, and hipcc's waits across branches are vmcnt(0)):
+        // a thread without a first quad re-reads the slab's last quad and never uses it (C % 16 == 0: 16 channels x HW
+        // floats behind x always hold 16 bytes)
+        long long p0 = lo + threadIdx.x * 4;
+        p0 = p0 < hi - 4 ? p0 : hi - 4;
+        const float* src = HW >= 4 ? xp + (p0 > 0 ? p0 : 0) : x;
+        const long long cs = HW >= 4 ? HW : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c4_first[k] = *reinterpret_cast<const f32x4*>(src + (long long)k * cs);
+        asm volatile("" ::: "memory");
+    };
     // per-channel (mean, rstd): one group per octet when the groups are whole octets; otherwise
     // (GroupNorm32 at widths 32 ... 128: 1 / 2 / 4 channels per group; concatenated inputs of 192 /
     // 384 channels: 6 / 12) the octet spans several groups (partials route only)
     float mu[8], rstd[8];
     if constexpr (!OS) {
+        issue_first();
         const int ng = (c0 + 7) / cpg - g + 1;
         for (int j = 0; j < ng; ++j) {
             const int gj = g + j;
@@ -418,20 +441,30 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
         const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> 3) + ((cg0 - os.c0) >> 3)) * slots
                               : os.p0 + ((long long)b * (os.c0 >> 3) + (cg0 >> 3)) * slots;
         const int n_ent = (cpg >> 3) * slots;
-        const double P0 = (double)e[0].x;
+        const float P0f = e[0].x;
         double N = 0.0, S = 0.0, Q = 0.0;
-        for (int base = threadIdx.x; base < n_ent; base += 256 * 4) {
-            f32x4 v[4];
+        f32x4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                v[k] = base + 256 * k < n_ent ? e[base + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; ++k)
+            v[k] = (int)threadIdx.x + 256 * k < n_ent ? e[threadIdx.x + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        issue_first();                                            // the x loads ride behind the first batch of entries
+        const double P0 = (double)P0f;
+        auto fold4 = [&](const f32x4 (&w)[4]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double n = v[k].y, d = (double)v[k].x - P0, s_ = v[k].z;
+            for (int k = 0; k < 4; ++k) {                         // an absent entry (n = 0) adds nothing
+                const double n = w[k].y, d = (double)w[k].x - P0, s_ = w[k].z;
                 N += n;
                 S += s_ + n * d;
-                Q += (double)v[k].w + d * (2.0 * s_ + n * d);
+                Q += (double)w[k].w + d * (2.0 * s_ + n * d);
             }
+        };
+        fold4(v);                                                 // straight-line: waits for the entries only (vmcnt(8))
+        for (int base = threadIdx.x + 256 * 4; base < n_ent; base += 256 * 4) {   // > 1024 entries per group: 64 x 2048 images
+            f32x4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w[k] = base + 256 * k < n_ent ? e[base + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            fold4(w);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -461,12 +494,8 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     const float seen = range->amax_scaled;
     float am = 0.0f;
     const int C8 = C >> 3;
-    const float* xp = x + b * x_bs + (long long)c0 * HW;
     half8_t* yh = ysp + b * ysp_bs + (long long)oct * HW;
     half8_t* yl = yh + (long long)C8 * HW;
-    const long long per = (HW + gridDim.x - 1) / gridDim.x;
-    const long long lo = blockIdx.x * per;
-    const long long hi = lo + per < HW ? lo + per : HW;
     auto one = [&](const float (&v)[8], half8_t& h8, half8_t& l8) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
@@ -484,13 +513,14 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
             h8[k] = ph.x; h8[k + 1] = ph.y; l8[k] = pl.x; l8[k + 1] = pl.y;
         }
     };
-    const bool vec = (HW & 3) == 0 && (per & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0;
     if (vec) {
         // four consecutive pixels per thread: 8 float4 channel loads, 2 x 4 contiguous 16-byte stores
         for (long long p = lo + threadIdx.x * 4; p < hi; p += 1024) {
             f32x4 c4[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c4[k] = *reinterpret_cast<const f32x4*>(xp + (long long)k * HW + p);
+            for (int k = 0; k < 8; ++k)
+                c4[k] = p == lo + threadIdx.x * 4 ? c4_first[k]
+                                                  : *reinterpret_cast<const f32x4*>(xp + (long long)k * HW + p);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[8];

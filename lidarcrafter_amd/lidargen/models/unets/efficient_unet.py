@@ -301,7 +301,7 @@ class EfficientUNet(nn.Module):
         cat1 = cat_buf(2 * C[1], H, W)
         cat2 = cat_buf(2 * C[2], H // 2, W // 2)
         cat3 = cat_buf(2 * C[3], H // 4, W // 4)
-        h = self.in_conv(buf)
+        h = self.in_conv(buf, emit_stats=True)      # feeds d_block1's first GroupNorm: no statistics pass
         h1 = self.d_block1(h, temb, ssd["d_block1"], out=K.chan_slice(cat1, C[1], 2 * C[1]))
         h2 = self.d_block2(h1, temb, ssd["d_block2"], out=K.chan_slice(cat2, C[2], 2 * C[2]))
         h3 = self.d_block3(h2, temb, ssd["d_block3"], out=K.chan_slice(cat3, C[3], 2 * C[3]))
