@@ -502,6 +502,8 @@ int lc_project_points_f64(const double* points, int N, int H, int W, double fov_
  * (points_in_boxes_cpu: int32 [N_box, M] 0/1, MARGIN 1e-2) and
  * src/roiaware_pool3d_kernel.cu:23-36,313-336 (points_in_boxes_gpu: int32 [B, M] index of the
  * first containing box or -1, MARGIN 1e-5).  boxes [.., 7] = x,y,z,dx,dy,dz,heading.
+ * The boxes of a block sit in LDS with their per-box constants (rotation, half extents): at most
+ * 1250 boxes per call / per sample (LC_EUNSUP beyond; the reference's scenes hold tens).
  * ------------------------------------------------------------------------------------------- */
 int lc_points_in_boxes_mask(const float* boxes, int n_boxes, const float* pts, int n_pts,
                             float margin, int32_t* out_mask, lc_stream_t s);

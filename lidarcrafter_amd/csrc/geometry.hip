@@ -55,7 +55,11 @@ __global__ __launch_bounds__(256) void project_scatter_kernel(const float* __res
     if (cells) { cells[2 * i] = gh; cells[2 * i + 1] = gw; }
     if (depth != depth) return;  // NaN never wins (numpy argsort puts NaN last -> overwritten)
     const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned)i;
-    atomicMin(zb + (long long)gh * W + gw, key);
+    // Dense clouds (4 M points on 32 x 1024 cells: ~128 candidates per cell) serialise on same-address 64-bit atomics in
+    // L2.  A cell's key only ever decreases, so a candidate that does not beat the value read a moment ago (an L2 read:
+    // agent-scope relaxed load, never a stale L1 line that would merely filter less) can be dropped without the atomic.
+    unsigned long long* cell = zb + (long long)gh * W + gw;
+    if (key < __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell, key);
 }
 
 // RESET: the cell is handed back empty (~0), so a caller-owned z-buffer needs no clear launch before the
@@ -151,27 +155,46 @@ __global__ __launch_bounds__(256) void project64_gather_kernel(const double* __r
 }
 
 // roiaware_pool3d.cpp:121-140 / roiaware_pool3d_kernel.cu:16-36: float rotation, double compares.
-__device__ __forceinline__ int pt_in_box(float x, float y, float z, const float* bx, float margin) {
-    const float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5], rz = bx[6];
-    if ((double)fabsf(z - cz) > (double)dz / 2.0) return 0;
-    const float cosa = (float)cos((double)(-rz)), sina = (float)sin((double)(-rz));
-    const float sx = x - cx, sy = y - cy;
+// Per-box constants live in LDS, 12 floats per box: (cx, cy, cz, cosa, sina, -, hz, hx, hy as three doubles from
+// float 6): the reference evaluates cos(-rz) / sin(-rz) in double and rounds to float, and compares |.| against
+// (double)d / 2.0 (+ (double)margin) -- all of that depends on the box only, so it is computed ONCE per block here
+// (round 5; before, every (point, box) pair paid two fp64 transcendentals: 13 boxes x 4 M points = 1.37 TB/s
+// "algorithmic").  Same expressions, same roundings: bit-exact with the per-pair form.
+constexpr int PIB_BOX = 12;
+__device__ __forceinline__ void pib_stage_boxes(const float* __restrict__ boxes, int nb, float margin, float* sb) {
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        const float* bx = boxes + 7 * k;
+        float* o = sb + PIB_BOX * k;
+        const float rz = bx[6];
+        o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2];
+        o[3] = (float)cos((double)(-rz)); o[4] = (float)sin((double)(-rz)); o[5] = 0.f;
+        double* d = reinterpret_cast<double*>(o + 6);
+        d[0] = (double)bx[5] / 2.0;                         // |z - cz| >  hz  -> outside
+        d[1] = (double)bx[3] / 2.0 + (double)margin;        // |lx|     <  hx
+        d[2] = (double)bx[4] / 2.0 + (double)margin;        // |ly|     <  hy
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ int pt_in_box(float x, float y, float z, const float* o) {
+    const double* d = reinterpret_cast<const double*>(o + 6);
+    if ((double)fabsf(z - o[2]) > d[0]) return 0;
+    const float cosa = o[3], sina = o[4];
+    const float sx = x - o[0], sy = y - o[1];
     const float lx = sx * cosa + sy * (-sina);
     const float ly = sx * sina + sy * cosa;
-    return ((double)fabsf(lx) < (double)dx / 2.0 + (double)margin) &
-           ((double)fabsf(ly) < (double)dy / 2.0 + (double)margin);
+    return ((double)fabsf(lx) < d[1]) & ((double)fabsf(ly) < d[2]);
 }
 
 __global__ __launch_bounds__(256) void pib_mask_kernel(const float* __restrict__ boxes, int nb,
                                                       const float* __restrict__ pts, int np,
                                                       float margin, int* __restrict__ out) {
-    extern __shared__ float sb[];
-    for (int i = threadIdx.x; i < nb * 7; i += 256) sb[i] = boxes[i];
-    __syncthreads();
+    extern __shared__ double sb_d[];
+    float* sb = reinterpret_cast<float*>(sb_d);
+    pib_stage_boxes(boxes, nb, margin, sb);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= np) return;
     const float x = pts[3ll * j], y = pts[3ll * j + 1], z = pts[3ll * j + 2];
-    for (int k = 0; k < nb; ++k) out[(long long)k * np + j] = pt_in_box(x, y, z, sb + 7 * k, margin);
+    for (int k = 0; k < nb; ++k) out[(long long)k * np + j] = pt_in_box(x, y, z, sb + PIB_BOX * k);
 }
 
 // [N,4] points (x, y, z, intensity): mask rows like points_in_boxes_cpu and, per point, the number
@@ -180,15 +203,15 @@ __global__ __launch_bounds__(256) void pib_mask4_kernel(const float* __restrict_
                                                        const float* __restrict__ pts, int np,
                                                        float margin, int* __restrict__ out_mask,
                                                        int* __restrict__ out_count) {
-    extern __shared__ float sb[];
-    for (int i = threadIdx.x; i < nb * 7; i += 256) sb[i] = boxes[i];
-    __syncthreads();
+    extern __shared__ double sb_d[];
+    float* sb = reinterpret_cast<float*>(sb_d);
+    pib_stage_boxes(boxes, nb, margin, sb);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= np) return;
     const f32x4 p = *reinterpret_cast<const f32x4*>(pts + 4ll * j);
     int cnt = 0;
     for (int k = 0; k < nb; ++k) {
-        const int in = pt_in_box(p.x, p.y, p.z, sb + 7 * k, margin);
+        const int in = pt_in_box(p.x, p.y, p.z, sb + PIB_BOX * k);
         if (out_mask) out_mask[(long long)k * np + j] = in;
         cnt += in;
     }
@@ -198,17 +221,17 @@ __global__ __launch_bounds__(256) void pib_mask4_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void pib_index_kernel(const float* __restrict__ boxes, int nb,
                                                        const float* __restrict__ pts, int np,
                                                        float margin, int* __restrict__ out) {
-    extern __shared__ float sb[];
+    extern __shared__ double sb_d[];
+    float* sb = reinterpret_cast<float*>(sb_d);
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < nb * 7; i += 256) sb[i] = boxes[(long long)b * nb * 7 + i];
-    __syncthreads();
+    pib_stage_boxes(boxes + (long long)b * nb * 7, nb, margin, sb);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= np) return;
     const float* p = pts + ((long long)b * np + j) * 3;
     const float x = p[0], y = p[1], z = p[2];
     int idx = -1;
     for (int k = 0; k < nb; ++k)
-        if (pt_in_box(x, y, z, sb + 7 * k, margin)) { idx = k; break; }
+        if (pt_in_box(x, y, z, sb + PIB_BOX * k)) { idx = k; break; }
     out[(long long)b * np + j] = idx;
 }
 
@@ -292,9 +315,9 @@ extern "C" int lc_project_points_f64(const double* points, int N, int H, int W, 
 extern "C" int lc_points_in_boxes_mask(const float* boxes, int n_boxes, const float* pts, int n_pts,
                                        float margin, int32_t* out_mask, lc_stream_t s) {
     if (!boxes || !pts || !out_mask || n_boxes <= 0 || n_pts <= 0) return LC_EINVAL;
-    if (n_boxes * 7 * sizeof(float) > 60000) return LC_EUNSUP;
+    if (n_boxes * PIB_BOX * sizeof(float) > 60000) return LC_EUNSUP;
     hipLaunchKernelGGL(pib_mask_kernel, dim3((n_pts + 255) / 256), dim3(256),
-                       n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
+                       n_boxes * PIB_BOX * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
                        out_mask);
     return lc_launch_status();
 }
@@ -302,9 +325,9 @@ extern "C" int lc_points_in_boxes_mask(const float* boxes, int n_boxes, const fl
 extern "C" int lc_points_in_boxes_index(const float* boxes, const float* pts, int B, int n_boxes,
                                         int n_pts, float margin, int32_t* out_idx, lc_stream_t s) {
     if (!boxes || !pts || !out_idx || B <= 0 || n_boxes <= 0 || n_pts <= 0) return LC_EINVAL;
-    if (n_boxes * 7 * sizeof(float) > 60000) return LC_EUNSUP;
+    if (n_boxes * PIB_BOX * sizeof(float) > 60000) return LC_EUNSUP;
     hipLaunchKernelGGL(pib_index_kernel, dim3((n_pts + 255) / 256, B), dim3(256),
-                       n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
+                       n_boxes * PIB_BOX * sizeof(float), lc_s(s), boxes, n_boxes, pts, n_pts, margin,
                        out_idx);
     return lc_launch_status();
 }
@@ -314,9 +337,9 @@ extern "C" int lc_points_in_boxes_mask4(const float* boxes, int n_boxes, const f
                                         lc_stream_t s) {
     if (!boxes || !pts4 || (!out_mask && !out_count) || n_boxes <= 0 || n_pts <= 0) return LC_EINVAL;
     if (reinterpret_cast<uintptr_t>(pts4) & 15) return LC_EINVAL;
-    if (n_boxes * 7 * sizeof(float) > 60000) return LC_EUNSUP;
+    if (n_boxes * PIB_BOX * sizeof(float) > 60000) return LC_EUNSUP;
     hipLaunchKernelGGL(pib_mask4_kernel, dim3((n_pts + 255) / 256), dim3(256),
-                       n_boxes * 7 * sizeof(float), lc_s(s), boxes, n_boxes, pts4, n_pts, margin,
+                       n_boxes * PIB_BOX * sizeof(float), lc_s(s), boxes, n_boxes, pts4, n_pts, margin,
                        out_mask, out_count);
     return lc_launch_status();
 }
