@@ -24,6 +24,8 @@ for shape in args:
     ks = v[5] if len(v) > 5 else 3
     x = torch.randn(B, Ci, H, W, device=dev)
     w = torch.randn(Co, Ci, ks, ks, device=dev) / (Ci * ks * ks) ** 0.5
+    if "--zeros" in sys.argv:      # same instruction stream on zero operands: what the power limit costs (DVFS)
+        x, w = x * 0 + 1e-30, w * 0
     b = torch.randn(Co, device=dev)
     pk = K.PackedConv()
     out = torch.empty(B, Co, H, W, device=dev)

@@ -1036,6 +1036,9 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                   "lc_conv1x1_f16x2_ps_fwd")
         return out
     ks = splitk_factor(B, Ci, Co, H, W) if tile_cfg == 0 else 0
+    sk_cfg = 0
+    if _SPLITK_FORCE and tile_cfg == 0 and Ci >= _SPLITK_FORCE[2]:       # developer switch: "ks:cfg[:min_ci]"
+        ks, sk_cfg = _SPLITK_FORCE[0], _SPLITK_FORCE[1]
     with _Timed("conv3x3", 2.0 * B * H * W * Co * Ci * 9,     # (pre-split x: 2 fp16 planes = 4 bytes per element too)
                 rd=4.0 * (B * Ci * H * W + Co * Ci * 9 + (B * Co * H * W if res is not None else 0)),
                 wr=4.0 * B * Co * H * W):
@@ -1047,7 +1050,7 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
             # small grid: ksplit blocks per tile over disjoint K ranges + one deterministic reduce
             part = torch.empty((ks, B, Co, H, W), device=dev, dtype=_F32)
             check(_conv_lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
-                                                    None, None, 0, None, 0, B, Ci, Co, H, W, 1.0, 0,
+                                                    None, None, 0, None, 0, B, Ci, Co, H, W, 1.0, sk_cfg,
                                                     None, part.data_ptr(), ks,
                                                     packed.wmeta.data_ptr(), packed.range_ptr(dev),
                                                     _stream()), "lc_conv2d_ring_f16x2_ps_fwd")
@@ -1078,6 +1081,8 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
 # 1-2 at the deep levels), its K range is divided over several blocks per tile.
 SPLITK = _os.environ.get("LC_SPLITK", "1") != "0"
 SPLITK_MAX_BLOCKS = int(_os.environ.get("LC_SPLITK_MAX_BLOCKS", "64"))
+_SPLITK_FORCE = tuple(int(v) for v in (_os.environ["LC_SPLITK_FORCE"] + ":0").split(":")[:3]) \
+    if _os.environ.get("LC_SPLITK_FORCE") else None
 
 
 def splitk_factor(B: int, Ci: int, Co: int, H: int, W: int) -> int:
