@@ -157,7 +157,11 @@ typedef struct lc_gn_stats_input {
  * lc_pack_conv_weight_f16x2's callers in lidarcrafter_amd.ops make (LC_EINVAL otherwise); and a sample of the input,
  * of the output and of the residual is addressed with 32-bit byte offsets: Ci*H*W*4, Co*H*W*4 < 2^31 (LC_EUNSUP).
  * tile_cfg 33 = the ping-pong kernel (csrc/conv_f16x2_pp.h): 3x3, Ci % 16 == 0, 64 <= Ci <= 512, Co % 64 == 0,
- * H % 4 == 0, W % 64 == 0 (LC_EUNSUP otherwise); the heuristic (tile_cfg 0) picks it only with LC_PP_MIN_STRIPS set. */
+ * H % 4 == 0, W % 64 == 0 (LC_EUNSUP otherwise); the heuristic (tile_cfg 0) picks it only with LC_PP_MIN_STRIPS set.
+ * tile_cfg 27 (round 5) = the tall kernel (csrc/conv_f16x2_tall.hip: halo rows kept in LDS across the block's walk down H,
+ * 64-bit input loads): 3x3, Ci 32 or 64, H % 4 == 0, W % 64 == 0; any other shape given this id runs on the pipelined
+ * 64 co x (4 x 64 px) tile (23), whose statistics partition it shares.  The heuristic picks 27 wherever it would pick 23 and
+ * the shape qualifies (LC_TALL=0: never). */
 int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void* wp_hi, const void* wp_lo,
                              const float* bias, const float* res, int64_t res_bs, float* y,
                              int64_t y_bs, int B, int Ci, int Co, int H, int W, int ks,
@@ -189,7 +193,7 @@ int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H, int W, in
  * already multiplied by the CONSUMER layer's x_scale (`range`, whose amax_scaled it maintains: the
  * range-safety contract of lc_conv_range moves to the producer).  lc_conv2d_ring_f16x2_ps_fwd then
  * stages its tiles with LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPRs, no VALU, no ds_write in
- * the K loop.  3x3 ring convolution, pipelined tile shapes (tile_cfg 0 = auto, 12/13/15/22/23/25/26/28);
+ * the K loop.  3x3 ring convolution, pipelined tile shapes (tile_cfg 0 = auto, 12/13/15/22/23/25/28);
  * wp_lo must be wp_hi + one plane (ONE allocation holding both planes of
  * lc_pack_conv_weight_f16x2).  Everything else as lc_conv2d_ring_f16x2_fwd. */
 int64_t lc_split_act_units(int B, int C, int H, int W);
