@@ -42,7 +42,7 @@ using namespace lcconv;
 
 #ifndef LC_TALL_ABL
 #define LC_TALL_ABL 0     // developer ablation (wrong results): 1 no x loads, 2 no staging arithmetic, 4 no MFMAs,
-                          // 8 no deferred epilogue (nothing is stored), 16 no weight DMA in the K loop, 32 no drain of the last tile
+                          // 8 no deferred epilogue (nothing is stored), 16 no weight DMA in the K loop, 32 no drain of the last tile, 64 half of the fragment reads
 #endif
 #ifndef LC_TALL_DMA_ASM
 #define LC_TALL_DMA_ASM 1 // weight LDS-DMA through inline assembly (see dma_w)
@@ -275,6 +275,25 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
     set_tile(h00, true);
     load_x(xset[0], 0);                                    // chunk n lives in register set n & 1
     if (AH == 2) load_x(xset[1], 1);
+    // ... and the loads of the block's top rows (staged behind the GroupNorm fold below): NTR rounds of 4 x 64 bits
+    constexpr int NTOP = NCH * 2 * 2 * 2 * 34, NTR = (NTOP + G::NT - 1) / G::NT;
+    u2_t tv[NTR][4];
+#pragma unroll
+    for (int rd = 0; rd < NTR; ++rd) {
+        const int t = tid + rd * G::NT;
+        const int pp = t % 34;
+        int u = t / 34;
+        const int row = u & 1; u >>= 1;
+        const int hf = u & 1; u >>= 1;
+        const int cb = u & 1;
+        const int c = u >> 1;
+        const int gh = h00 - 1 + row;
+        int gw = w0 - 2 + 2 * pp;
+        gw = gw < 0 ? gw + W : (gw >= W ? gw - W : gw);
+        const unsigned vo = (t < NTOP && gh >= 0) ? (unsigned)((c * 16 + cb * 8 + hf * 4) * HW + gh * W + gw) * 4u : XOOB;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[rd][k] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vo, (unsigned)k * (unsigned)HW * 4u, 0);
+    }
     if constexpr (GNM != 0) {   // rows of the fused input norm (as conv_f16x2_pipe_kernel), repacked per channel pair
         if (a.gs.partials) {
             for (int i = tid; i < a.Cgn; i += G::NT) ctab[i] = gn_row_from_stats(a.gs, xptr, b, i, a.Ci, HW);
@@ -297,24 +316,19 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
     }
     __syncthreads();                                       // bias_s and the rows visible
     // the first tile's rows 0,1 (image rows h0 - 1, h0) of every chunk -> keep[0][c]: tasks (chunk, cb, half, row,
-    // aligned pair p = columns w0 - 2 + 2 p, + 1 of which columns -1 .. 64 of the tile are used).  Once per block.
-    {
-        constexpr int NTOP = NCH * 2 * 2 * 2 * 34;
-        for (int t = tid; t < NTOP; t += G::NT) {
+    // aligned pair p = columns w0 - 2 + 2 p, + 1 of which columns -1 .. 64 of the tile are used).  Once per block; their
+    // loads were issued in front of the GroupNorm fold (top_load), all NTR rounds at once.
+#pragma unroll
+    for (int rd = 0; rd < NTR; ++rd) {
+        const int t = tid + rd * G::NT;
+        if (t < NTOP) {
             const int pp = t % 34;
             int u = t / 34;
             const int row = u & 1; u >>= 1;
             const int hf = u & 1; u >>= 1;
             const int cb = u & 1;
             const int c = u >> 1;
-            const int gh = h00 - 1 + row;
-            const bool ok = gh >= 0;
-            int gw = w0 - 2 + 2 * pp;
-            gw = gw < 0 ? gw + W : (gw >= W ? gw - W : gw);
-            const unsigned vo = ok ? (unsigned)((c * 16 + cb * 8 + hf * 4) * HW + gh * W + gw) * 4u : XOOB;
-            u2_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vo, (unsigned)k * (unsigned)HW * 4u, 0);
+            const bool ok = h00 - 1 + row >= 0;
             f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
             if constexpr (GNM != 0) {
                 const f32x4* g = ok ? ctab + c * 8 + cb * 4 + hf * 2 : ctab + (a.Cgn >> 1);
@@ -324,8 +338,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
             for (int e = 0; e < 2; ++e) {
                 const int uc = 2 * pp - 1 + e;
                 h2_t h0, l0, h1, l1;
-                stage_pair2(__uint_as_float(v[0][e]), __uint_as_float(v[1][e]), r0, h0, l0);
-                stage_pair2(__uint_as_float(v[2][e]), __uint_as_float(v[3][e]), r1, h1, l1);
+                stage_pair2(__uint_as_float(tv[rd][0][e]), __uint_as_float(tv[rd][1][e]), r0, h0, l0);
+                stage_pair2(__uint_as_float(tv[rd][2][e]), __uint_as_float(tv[rd][3][e]), r1, h1, l1);
                 if (uc >= 0 && uc < RS) {
                     char* d = ldsb + ((G::KEEP0 + c * RPU + cb * CBS + row * RS + uc) * 16 + hf * 8);
                     *reinterpret_cast<h4_t*>(d) = h4_t{h0.x, h0.y, h1.x, h1.y};
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
         for (int tap = 0; tap < NTAP; ++tap) {
             const int s = tap & 1;
             if (tap == LC_TALL_T0 - 1) { stage_rows(xst, NC); __builtin_amdgcn_sched_barrier(0); }   // rows ahead of the fragment fetch (no lgkmcnt(0))
-            if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
+            if (tap + 1 < NTAP && !((LC_TALL_ABL & 64) && (tap & 1))) fetch(tap + 1, s ^ 1);   // (64: every second tap re-uses stale fragments)
             __builtin_amdgcn_sched_barrier(0);
             if (!(LC_TALL_ABL & 8) && C * NTAP + tap < DE::NUSED) de.slot(C * NTAP + tap);
             // this tap's weight DMA piece BEHIND the deferred slot: the wait in front of the chunk barrier then leaves
