@@ -10,10 +10,19 @@
 //    first two staged rows are tile t's last two: they stay in LDS (per 16-channel chunk, two
 //    parities: 66 KB), so in steady state a tile stages 4 rows, not 6 -- 1.16x its own pixels
 //    instead of 1.55x: a third less GroupNorm / SiLU / split arithmetic and a third fewer loads.
-//  * 64-BIT x LOADS, TWO CHUNKS AHEAD.  A staging task is (2 adjacent pixels) x (4 channels): four
-//    `buffer_load_dwordx2` per thread and chunk (pipelined kernel: sixteen 32-bit loads), issued two
-//    K chunks before the chunk that stages them (two register sets of 9 registers, static parity);
-//    the two halo columns of the four new rows are one 32-bit load per wave (16 lanes x one element).
+//  * 64-BIT x LOADS BEHIND THE DMA.  A staging task is (2 adjacent pixels) x (4 channels): four
+//    `buffer_load_dwordx2` per thread and chunk (pipelined kernel: sixteen 32-bit loads) into one of
+//    two register sets (static parity); the two halo columns of the four new rows are one 32-bit load
+//    per wave (16 lanes x one element).  The loads of chunk g + 2 go out in chunk g, BEHIND its last
+//    weight-DMA piece, and are staged during chunk g + 1: the wait in front of the chunk barrier ("my
+//    DMA pieces have landed", an exact vmcnt) leaves them in flight.
+//  * WEIGHT DMA IN INLINE ASSEMBLY.  Through the builtin, hipcc orders every later ds_read behind
+//    the LDS-DMA: an `s_waitcnt vmcnt(1..2)` in front of each tap's fragment reads, i.e. every tap
+//    waited for the piece issued one tap earlier and -- VMEM returns in order -- for every deferred
+//    store before it (22 such waits per chunk in the first build).  See dma_w.
+//  The launch is power-limited (the same stream on zero operands runs 22-26 % faster): what pays is
+//  removed work, not re-placed work -- the developer switches below (tap positions, priorities,
+//  prefetch distance) all measure as noise (profiles/r05_level0.txt section 5).
 //
 // (First version of the round, measured and dropped -- profiles/r05_level0.txt: TRANSPOSED
 // accumulators, i.e. MFMA operands swapped so that a lane holds one channel x 4 consecutive pixels
