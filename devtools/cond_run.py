@@ -24,5 +24,5 @@ x = ddpm.sample(batch, B, S, progress=False, rng=rng, mode="ddim")
 torch.cuda.synchronize()
 print("ok", float(x.abs().mean()))
 if os.environ.get("LC_GN_TRACE"):
-    for k, v in sorted(K.GN_TRACE.items(), key=lambda kv: (kv[0][2], kv[0][0])):
+    for k, v in sorted(K.GN_TRACE.items(), key=lambda kv: (kv[0][2], kv[0][0], kv[0][3])):
         print("gn lookup", k, v)

@@ -1,5 +1,5 @@
 """Time the pre-split 3x3 conv (GroupNorm-apply output as hi / lo planes -> LDS-DMA kernel) on the C2 layer shapes.
-    LC_HIP_LIB=<variant> python devtools/ps_time.py [B] [--cfg N]"""
+    LC_HIP_LIB=<variant> python devtools/ps_time.py [B] [--cfg N] [--emit 0|8|4]   (statistics entries: none / octets / quads)"""
 import os
 import sys
 import time
@@ -10,7 +10,8 @@ import torch  # noqa: E402
 from lidarcrafter_amd import ops as K  # noqa: E402
 
 cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 0
-pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--cfg"]
+emit = int(sys.argv[sys.argv.index("--emit") + 1]) if "--emit" in sys.argv else 8
+pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] not in ("--cfg", "--emit")]
 B = int(pos[0]) if pos else 8
 dev = torch.device("cuda:0")
 for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 128), (256, 128, 16, 512)):
@@ -22,7 +23,7 @@ for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 12
     out = torch.empty(B, Co, H, W, device=dev)
     sa = K.groupnorm(x, 8, 1e-6, act_silu=True, split_for=pk)
     assert isinstance(sa, K.SplitAct)
-    f = lambda: K.conv2d_ring(sa, pk, w, b, out=out, res=res, out_scale=0.7071, emit_stats=True, tile_cfg=cfg)
+    f = lambda: K.conv2d_ring(sa, pk, w, b, out=out, res=res, out_scale=0.7071, emit_stats={0: False, 8: True}.get(emit, emit), tile_cfg=cfg)
     for _ in range(3):
         f()
     g = torch.cuda.CUDAGraph()
@@ -38,4 +39,4 @@ for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 12
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 20)
     fl = 2.0 * B * H * W * Ci * Co * 9
-    print(f"ps {B}:{Ci}:{Co}:{H}:{W} cfg {cfg}: {min(ts) * 1e6:.1f} us  {fl / min(ts) / 1e12:.0f} TF")
+    print(f"ps {B}:{Ci}:{Co}:{H}:{W} cfg {cfg} emit {emit}: {min(ts) * 1e6:.1f} us  {fl / min(ts) / 1e12:.0f} TF")

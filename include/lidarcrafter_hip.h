@@ -131,9 +131,11 @@ int lc_range_from_amax(const float* amax, int64_t n, float bound_mult, lc_conv_r
 typedef struct lc_oct_stats {
     const float* p;     /* [B, channels/unit, slots, 4] */
     int channels, slots;
-    int unit;           /* channels per entry: 8 (octets), or 2 (pairs: lc_conv2d_ring_f16x2_fwd with
-                           gn_ostats_unit = 2, for a GroupNorm with 2 / 4 / 6 channels per group; accepted
-                           by the conv's fused input norm, LC_EUNSUP in lc_groupnorm_apply_os*) */
+    int unit;           /* channels per entry: 8 (octets: the conv epilogues), 2 (pairs: lc_conv2d_ring_f16x2_fwd with
+                           gn_ostats_unit = 2, for a GroupNorm with 2 / 4 / 6 channels per group), 1 (single
+                           channels: lc_resample2x_stats_fwd), 4.  Every consumer -- the conv's fused input norm,
+                           lc_groupnorm_apply_os, lc_groupnorm_apply_os_split -- folds any of them as long as a
+                           group is a whole number of entries (round 5; before: octets only in the apply passes) */
 } lc_oct_stats;
 /* Input normalisation straight from the statistics (no lc_groupnorm_coeffs launch): the partials
  * of lc_groupnorm_stats over the conv's input plus the GroupNorm / AdaGN parameters; every block
@@ -209,7 +211,8 @@ int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const lc_oct_stats
 int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo,
                                 const float* bias, const float* res, int64_t res_bs, float* y,
                                 int64_t y_bs, int B, int Ci, int Co, int H, int W, float out_scale,
-                                int tile_cfg, float* gn_ostats_out,
+                                int tile_cfg, float* gn_ostats_out /* NULL, or [B, Co / unit, slots, 4] */,
+                                int gn_ostats_unit /* 8 = octet entries, 4 = quad entries (else LC_EUNSUP) */,
                                 float* splitk_part /* NULL, or [ksplit, B, Co, H, W] */, int ksplit,
                                 const float* wmeta, lc_conv_range* range, lc_stream_t s);
 /* 1x1 convolution of a pre-split activation (the same planes; H * W is one pixel axis): LDS-DMA staging, 128 output
@@ -286,6 +289,13 @@ int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_stats* s0, 
  * ------------------------------------------------------------------------------------------- */
 int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H,
                       int W, int dir, lc_stream_t s);
+/* Down-sampling that also leaves GroupNorm statistics of its OUTPUT (round 5): one entry per (sample, channel, slot) in
+ * the producer-statistics format with unit = 1 -- ostats[B, C, slots, 4], slots = lc_resample2x_stats_slots(H, W, -1)
+ * (0: the shape takes the scalar kernel, which leaves none; lc_resample2x_stats_fwd then returns LC_EUNSUP).  The
+ * GroupNorm behind a Resample(down=2) (efficient_unet.py:141-143 -> :79) folds them instead of taking a statistics pass. */
+int64_t lc_resample2x_stats_slots(int H, int W, int dir);
+int lc_resample2x_stats_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H,
+                            int W, int dir, float* ostats, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Small dense layer  y[m, n] = sum_k act(x[m,k]) * w[n,k] + b[n]   (w in nn.Linear layout).

@@ -64,7 +64,7 @@ SIGNATURES = {
                                           i32, i32, f32, i32, vp, vp]),
     "lc_conv1x1_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "lc_conv2d_ring_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32,
-                                          f32, i32, vp, vp, i32, vp, vp, vp]),
+                                          f32, i32, vp, i32, vp, i32, vp, vp, vp]),
     "lc_range_from_tensor": (i32, [vp, i64, i32, i64, vp, vp]),
     "lc_splitk_stats_slots": (i64, [i32, i32]),
     "lc_splitk_reduce": (i32, [vp, i32, vp, vp, i64, vp, i64, i32, i32, i32, i32, f32, vp, vp]),
@@ -89,6 +89,8 @@ SIGNATURES = {
     "lc_groupnorm_bwd_train": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp,
                                      i32, i32, i32, i32, i32, i32, vp, vp]),
     "lc_resample2x_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "lc_resample2x_stats_slots": (i64, [i32, i32, i32]),
+    "lc_resample2x_stats_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
     "lc_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "lc_sinusoid_fwd": (i32, [vp, vp, i32, i32, f32, vp]),
     "lc_attention_fwd": (i32, [_op, _op, _op, _op, _op, _op, _op, _op, vp, i64, i64, i64,

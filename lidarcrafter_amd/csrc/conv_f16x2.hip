@@ -1036,20 +1036,33 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
             }
         }
         if constexpr (EMIT_STATS && !(LC_EMIT_ABL & 2)) {
+            // One 32-bit buffer store per entry, fields spread over the four lanes below the reducing lane (round 5: the
+            // first form -- four volatile 32-bit stores from that lane -- compiled to sc0 sc1 stores with a vmcnt(0) behind
+            // each, i.e. every entry waited for all of the tile's output stores: +6 ... +11 us per launch,
+            // profiles/r05_level0.txt section 7).  Octet entries: lane 63 holds the sums; quad entries (a consumer
+            // GroupNorm with 4 / 12 channels per group): lanes 0-31 hold channels 8m .. 8m+3, lanes 32-63 8m+4 .. 8m+7
+            // -- the two half-wave sums in lanes 31 / 63, one pivot.
             const int slot = ((h0 / C::TH_) * a.tiles_w + w0 / C::TW_) * C::WPX_ + wpx;
             const int co_blk = co0 + wco * C::TCO_ * 32;
+            const bool quads = a.ounit == 4;
+            const int ush = quads ? 2 : 3;
+            const unsigned ebytes = (unsigned)(a.Co >> ush) * (unsigned)a.oslots * 16u;
+            const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.ostats + (long long)b * (a.Co >> ush) * a.oslots), 0, ebytes, 0x00020000);
+            const bool mine = quads ? (lane & 31) >= 28 : lane >= 60;
+            const float nv = (float)((quads ? 4 : 8) * nvalid);
 #pragma unroll
             for (int i = 0; i < C::TCO_; ++i) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int co_oct = co_blk + i * 32 + 8 * m;
-                    const float s_ = wave_sum_to_lane63(st_s[i][m]);
-                    const float q_ = wave_sum_to_lane63(st_q[i][m]);
-                    if (lane == 63 && co_oct < a.Co) {          // four 32-bit stores: see the hazard note at DefEpi
-                        volatile float* ep = reinterpret_cast<volatile float*>(
-                            &a.ostats[((long long)b * (a.Co >> 3) + (co_oct >> 3)) * a.oslots + slot]);
-                        ep[0] = st_p[i][m]; ep[1] = (float)(8 * nvalid); ep[2] = s_; ep[3] = q_;
-                    }
+                    const float sh = half_sum_to_lane31_63(st_s[i][m]), qh = half_sum_to_lane31_63(st_q[i][m]);
+                    const float sf = dpp_add<0x143, 0xC>(sh), qf = dpp_add<0x143, 0xC>(qh);   // lane 63: the wave's sum
+                    const int ent = quads ? (co_oct >> 2) + (lane >> 5) : (co_oct >> 3);
+                    const unsigned vo = (mine && co_oct < a.Co)
+                                            ? ((unsigned)ent * (unsigned)a.oslots + (unsigned)slot) * 16u + 4u * (lane & 3)
+                                            : 0x80000000u;
+                    store_entry_4lanes(rs_o, st_p[i][m], nv, quads ? sh : sf, quads ? qh : qf, vo);
                 }
             }
         }
@@ -1514,10 +1527,11 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
             if (s1 && (!s1->p || s1->channels <= 0 || s1->slots <= 0)) return LC_EINVAL;
             const int c0 = s0->channels, c1 = s1 ? s1->channels : 0, cpg = Ci / gn_stats->G;
             const int u0 = s0->unit, u1 = s1 ? s1->unit : u0;
-            if ((u0 != 8 && u0 != 2) || (u1 != 8 && u1 != 2)) return LC_EINVAL;
+            auto ush_of = [](int u) { return u == 8 ? 3 : (u == 4 ? 2 : (u == 2 ? 1 : (u == 1 ? 0 : -1))); };
+            if (ush_of(u0) < 0 || ush_of(u1) < 0) return LC_EINVAL;      // entries per octet / quad / pair / channel
             if (c0 + c1 != Ci || cpg % u0 || cpg % u1 || c0 % cpg || gn_stats->G > GN_MAX_G) return LC_EUNSUP;
-            a.seg[0] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s0->p), c0, s0->slots, u0 == 8 ? 3 : 1};
-            if (s1) a.seg[1] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s1->p), c1, s1->slots, u1 == 8 ? 3 : 1};
+            a.seg[0] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s0->p), c0, s0->slots, ush_of(u0)};
+            if (s1) a.seg[1] = ConvArgsH::OctSeg{reinterpret_cast<const f32x4*>(s1->p), c1, s1->slots, ush_of(u1)};
         }
         a.gs = *gn_stats;
         a.gs.os0 = a.gs.os1 = nullptr;
@@ -1568,7 +1582,7 @@ extern "C" int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H
 extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo,
                                            const float* bias, const float* res, int64_t res_bs,
                                            float* y, int64_t y_bs, int B, int Ci, int Co, int H, int W,
-                                           float out_scale, int tile_cfg, float* gn_ostats_out,
+                                           float out_scale, int tile_cfg, float* gn_ostats_out, int gn_ostats_unit,
                                            float* splitk_part, int ksplit, const float* wmeta,
                                            lc_conv_range* range, lc_stream_t s) {
     if (!x_split || !wp_hi || !wp_lo || (!y && !splitk_part) || !wmeta || !range || B <= 0 || Ci <= 0 ||
@@ -1600,8 +1614,9 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
     a.ostats = nullptr; a.oslots = 0; a.ounit = 8;
     if (gn_ostats_out && !splitk_part) {
         a.oslots = pipe_stat_slots(tile_cfg, H, W);
-        if (Co % 8) return LC_EUNSUP;
+        if (Co % 8 || (gn_ostats_unit != 8 && gn_ostats_unit != 4)) return LC_EUNSUP;   // octet or quad entries
         a.ostats = reinterpret_cast<f32x4*>(gn_ostats_out);
+        a.ounit = gn_ostats_unit;
     }
     return dispatch_h<3>(tile_cfg, a, lc_s(s));
 }

@@ -98,7 +98,7 @@ struct ConvArgsH {
     lc_gn_stats_input gs;     // (os0 / os1 are host pointers: the kernels read seg[] instead)
     // ... or the octet statistics the input's producer(s) emitted (gs.partials == NULL):
     // seg[0] covers channels [0, seg[0].channels), seg[1] the rest
-    struct OctSeg { const f32x4* p; int channels, slots, ush; } seg[2];   // ush: log2(channels per entry) = 3 or 1
+    struct OctSeg { const f32x4* p; int channels, slots, ush; } seg[2];   // ush: log2(channels per entry) = 3, 2, 1 or 0
     int tpb;   // pixel tiles per block (pipelined kernel): consecutive tiles of one sample
     int vert;  // 1: the block walks its tpb tiles down H (W-neighbours run concurrently), 0: along W
     int xcd;   // 1: blockIdx.x is remapped so that each XCD owns a contiguous range of tiles
@@ -336,6 +336,21 @@ __device__ __forceinline__ float half_sum_to_lane31_63(float v) {
     v = dpp_add<0x118, 0xF>(v);
     v = dpp_add<0x142, 0xA>(v);
     return v;
+}
+
+// One statistics entry (pivot, n, s, q) as ONE 32-bit buffer store: the sums sit in the reducing lane R (63, or 31 and 63
+// for two half-wave entries), pivot and count are wave-uniform; lanes R-3 .. R carry the fields 0 .. 3 (their voffset =
+// entry byte offset + 4 * (lane & 3); every other lane: an out-of-range offset).  No wide store data, no waits (DefEpi's
+// store_entry_lanes, for epilogues outside that struct).
+__device__ __forceinline__ void store_entry_4lanes(__amdgpu_buffer_rsrc_t rs, float p_, float n_, float s_, float q_,
+                                                   unsigned voffset) {
+    const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s_), 0x101, 0xF, 0xF, true));
+    const int f = (int)(threadIdx.x & 3);
+    const unsigned k0 = (unsigned)((f - 1) >> 31), k1 = (unsigned)(((f ^ 1) - 1) >> 31);
+    const unsigned k2 = (unsigned)(((f ^ 2) - 1) >> 31), k3 = (unsigned)(((f ^ 3) - 1) >> 31);
+    const unsigned vu = (__float_as_uint(p_) & k0) | (__float_as_uint(n_) & k1) | (__float_as_uint(s1) & k2) |
+                        (__float_as_uint(q_) & k3);
+    __builtin_amdgcn_raw_buffer_store_b32(vu, rs, voffset, 0, 0);
 }
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (descriptor + per-lane voffset + uniform

@@ -158,7 +158,29 @@ __global__ void gn_coeffs_kernel(const double* __restrict__ part, const float* _
 struct OctStats2 {
     const f32x4* p0; const f32x4* p1;     // segment 0: channels [0, c0), segment 1: [c0, c0 + c1)
     int c0, slots0, c1, slots1;
+    int ush0, ush1;                       // log2(channels per entry) of each segment: 3 octets, 2 quads, 1 pairs, 0 channels
 };
+// lc_oct_stats -> one OctStats2 segment; false: not a unit this library writes
+static bool os_unit_shift(int unit, int& ush) {
+    switch (unit) { case 8: ush = 3; return true; case 4: ush = 2; return true; case 2: ush = 1; return true;
+                    case 1: ush = 0; return true; default: return false; }
+}
+// The segments of a statistics-fed GroupNorm: every group must be whole entries of ONE segment.
+static int os_from_segments(const lc_oct_stats* s0, const lc_oct_stats* s1, int C, int cpg, OctStats2& os) {
+    if (!s0 || !s0->p || s0->channels <= 0 || s0->slots <= 0) return LC_EINVAL;
+    if (s1 && (!s1->p || s1->channels <= 0 || s1->slots <= 0)) return LC_EINVAL;
+    os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
+    os.p1 = nullptr; os.c1 = 0; os.slots1 = 0; os.ush0 = os.ush1 = 3;
+    if (!os_unit_shift(s0->unit, os.ush0)) return LC_EUNSUP;
+    if (s1) {
+        os.p1 = reinterpret_cast<const f32x4*>(s1->p); os.c1 = s1->channels; os.slots1 = s1->slots;
+        if (!os_unit_shift(s1->unit, os.ush1)) return LC_EUNSUP;
+    }
+    if (os.c0 + os.c1 != C || os.c0 % cpg || cpg % s0->unit || os.c0 % s0->unit ||
+        (s1 && (cpg % s1->unit || os.c1 % s1->unit)))
+        return LC_EUNSUP;
+    return LC_OK;
+}
 
 __global__ __launch_bounds__(256) void gn_apply_os_kernel(
     const float* __restrict__ x, long long x_bs, OctStats2 os, const float* __restrict__ gamma,
@@ -171,9 +193,10 @@ __global__ __launch_bounds__(256) void gn_apply_os_kernel(
     const int cg0 = g * cpg;                                   // first channel of the group
     const bool seg1 = cg0 >= os.c0;
     const int slots = seg1 ? os.slots1 : os.slots0;
-    const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> 3) + ((cg0 - os.c0) >> 3)) * slots
-                          : os.p0 + ((long long)b * (os.c0 >> 3) + (cg0 >> 3)) * slots;
-    const int n_ent = (cpg >> 3) * slots;
+    const int ush = seg1 ? os.ush1 : os.ush0;
+    const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> ush) + ((cg0 - os.c0) >> ush)) * slots
+                          : os.p0 + ((long long)b * (os.c0 >> ush) + (cg0 >> ush)) * slots;
+    const int n_ent = (cpg >> ush) * slots;
     const double P0 = (double)e[0].x;
     double N = 0.0, S = 0.0, Q = 0.0;
     for (int base = threadIdx.x; base < n_ent; base += 256 * 4) {   // 4 loads in flight per thread
@@ -381,7 +404,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
         lc_block_amax_store(am, amax_out + ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
-template <bool OS>
+// OS: 0 = statistics-pass partials; 1 = producer entries, groups of whole channel octets (the block folds ONE group);
+// 2 = producer entries, 2 or 4 channels per group (GroupNorm32 at 64 / 128 channels, round 5): the octet holds 4 / 2
+// groups, wave w of the block folds group w.
+template <int OS>
 __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     const float* __restrict__ x, long long x_bs, const double* __restrict__ part, OctStats2 os,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
@@ -434,13 +460,62 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
             for (int k = 0; k < 8; ++k)
                 if ((c0 + k) / cpg == gj) { mu[k] = m_; rstd[k] = r_; }
         }
+    } else if constexpr (OS == 2) {
+        __shared__ float shm[8];
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int ng = 8 / cpg;                                    // 4 or 2 groups in this octet
+        const int cg0 = (g + (wv < ng ? wv : ng - 1)) * cpg;       // (waves past the last group redo it: no divergence)
+        const bool seg1 = cg0 >= os.c0;
+        const int slots = seg1 ? os.slots1 : os.slots0;
+        const int ush = seg1 ? os.ush1 : os.ush0;
+        const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> ush) + ((cg0 - os.c0) >> ush)) * slots
+                              : os.p0 + ((long long)b * (os.c0 >> ush) + (cg0 >> ush)) * slots;
+        const int n_ent = (cpg >> ush) * slots;
+        const float P0f = e[0].x;
+        double N = 0.0, S = 0.0, Q = 0.0;
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lane + 64 * k < n_ent ? e[lane + 64 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        issue_first();
+        const double P0 = (double)P0f;
+        auto fold4 = [&](const f32x4 (&w)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double n = w[k].y, d = (double)w[k].x - P0, s_ = w[k].z;
+                N += n;
+                S += s_ + n * d;
+                Q += (double)w[k].w + d * (2.0 * s_ + n * d);
+            }
+        };
+        fold4(v);
+        for (int base = lane + 64 * 4; base < n_ent; base += 64 * 4) {
+            f32x4 w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = base + 64 * k < n_ent ? e[base + 64 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            fold4(w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            N += __shfl_xor(N, o, 64); S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64);
+        }
+        if (lane == 0) {
+            const double m = N > 0.0 ? S / N : 0.0;
+            double var = N > 0.0 ? Q / N - m * m : 0.0;
+            if (var < 0.0) var = 0.0;
+            shm[2 * wv] = (float)(P0 + m);
+            shm[2 * wv + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int j = k >> (cpg == 4 ? 2 : 1); mu[k] = shm[2 * j]; rstd[k] = shm[2 * j + 1]; }
     } else {
         const int cg0 = g * cpg;
         const bool seg1 = cg0 >= os.c0;
         const int slots = seg1 ? os.slots1 : os.slots0;
-        const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> 3) + ((cg0 - os.c0) >> 3)) * slots
-                              : os.p0 + ((long long)b * (os.c0 >> 3) + (cg0 >> 3)) * slots;
-        const int n_ent = (cpg >> 3) * slots;
+        const int ush = seg1 ? os.ush1 : os.ush0;
+        const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> ush) + ((cg0 - os.c0) >> ush)) * slots
+                              : os.p0 + ((long long)b * (os.c0 >> ush) + (cg0 >> ush)) * slots;
+        const int n_ent = (cpg >> ush) * slots;
         const float P0f = e[0].x;
         double N = 0.0, S = 0.0, Q = 0.0;
         f32x4 v[4];
@@ -633,19 +708,11 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
                                      const float* scale, const float* shift, int64_t ss_bs, float* y,
                                      int64_t y_bs, int B, int C, int H, int W, int G, float eps,
                                      int act_silu, lc_stream_t s) {
-    if (!x || !y || B <= 0 || G <= 0 || C % G || !s0 || !s0->p || s0->channels <= 0 || s0->slots <= 0)
-        return LC_EINVAL;
-    if (s0->unit != 8 || (s1 && s1->unit != 8)) return LC_EUNSUP;   // pair entries: fused conv input norm only
-    OctStats2 os;
-    os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
-    os.p1 = nullptr; os.c1 = 0; os.slots1 = 0;
-    if (s1) {
-        if (!s1->p || s1->channels <= 0 || s1->slots <= 0) return LC_EINVAL;
-        os.p1 = reinterpret_cast<const f32x4*>(s1->p); os.c1 = s1->channels; os.slots1 = s1->slots;
-    }
+    if (!x || !y || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const int cpg = C / G;
-    // octet-granular statistics: groups are whole octets and lie inside one segment
-    if (os.c0 + os.c1 != C || cpg % 8 || os.c0 % cpg || os.c0 % 8 || os.c1 % 8) return LC_EUNSUP;
+    OctStats2 os;
+    // groups are whole entries (octets, quads, pairs or single channels: round 5) and lie inside one segment
+    if (const int rc = os_from_segments(s0, s1, C, cpg, os)) return rc;
     const long long HW = (long long)H * W;
     int slabs = (int)((HW + 4095) / 4096);
     if (slabs < 1) slabs = 1;
@@ -688,8 +755,8 @@ extern "C" int lc_groupnorm_apply_split(const float* x, int64_t x_bs, const doub
     if (C % 16) return LC_EUNSUP;
     const long long HW = (long long)H * W;
     const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
-    OctStats2 os{nullptr, nullptr, 0, 0, 0, 0};
-    hipLaunchKernelGGL(gn_apply_split_kernel<false>, dim3(split_slabs(B, C, HW), C / 8, B), dim3(256), 0,
+    OctStats2 os{nullptr, nullptr, 0, 0, 0, 0, 3, 3};
+    hipLaunchKernelGGL(gn_apply_split_kernel<0>, dim3(split_slabs(B, C, HW), C / 8, B), dim3(256), 0,
                        lc_s(s), x, (long long)x_bs, partials, os, gamma, beta, scale, shift,
                        (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
                        (long long)2 * (C / 8) * HW, C, G, HW, nch, eps, act_silu, range);
@@ -702,24 +769,23 @@ extern "C" int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const l
                                            int64_t ss_bs, void* y_split, int B, int C, int H, int W,
                                            int G, float eps, int act_silu, lc_conv_range* range,
                                            lc_stream_t s) {
-    if (!x || !y_split || !range || B <= 0 || G <= 0 || C % G || !s0 || !s0->p || s0->channels <= 0 ||
-        s0->slots <= 0)
-        return LC_EINVAL;
-    if (s0->unit != 8 || (s1 && s1->unit != 8)) return LC_EUNSUP;
-    OctStats2 os;
-    os.p0 = reinterpret_cast<const f32x4*>(s0->p); os.c0 = s0->channels; os.slots0 = s0->slots;
-    os.p1 = nullptr; os.c1 = 0; os.slots1 = 0;
-    if (s1) {
-        if (!s1->p || s1->channels <= 0 || s1->slots <= 0) return LC_EINVAL;
-        os.p1 = reinterpret_cast<const f32x4*>(s1->p); os.c1 = s1->channels; os.slots1 = s1->slots;
-    }
+    if (!x || !y_split || !range || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     const int cpg = C / G;
-    if (os.c0 + os.c1 != C || cpg % 8 || os.c0 % cpg || os.c0 % 8 || os.c1 % 8 || C % 16) return LC_EUNSUP;
+    OctStats2 os;
+    if (const int rc = os_from_segments(s0, s1, C, cpg, os)) return rc;
+    // (a block of this kernel owns a channel OCTET: groups of whole octets -- one (mean, rstd) per block -- or 2 / 4
+    // channels per group -- one group per wave --, whatever the entries' unit)
+    if ((cpg % 8 && cpg != 2 && cpg != 4) || os.c0 % 8 || C % 16) return LC_EUNSUP;
     const long long HW = (long long)H * W;
-    hipLaunchKernelGGL(gn_apply_split_kernel<true>, dim3(split_slabs(B, C, HW), C / 8, B), dim3(256), 0,
-                       lc_s(s), x, (long long)x_bs, nullptr, os, gamma, beta, scale, shift,
-                       (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
-                       (long long)2 * (C / 8) * HW, C, G, HW, 0, eps, act_silu, range);
+    const dim3 grid(split_slabs(B, C, HW), C / 8, B);
+    if (cpg % 8 == 0)
+        hipLaunchKernelGGL(gn_apply_split_kernel<1>, grid, dim3(256), 0, lc_s(s), x, (long long)x_bs, nullptr, os, gamma,
+                           beta, scale, shift, (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
+                           (long long)2 * (C / 8) * HW, C, G, HW, 0, eps, act_silu, range);
+    else
+        hipLaunchKernelGGL(gn_apply_split_kernel<2>, grid, dim3(256), 0, lc_s(s), x, (long long)x_bs, nullptr, os, gamma,
+                           beta, scale, shift, (long long)ss_bs, reinterpret_cast<half8_t*>(y_split),
+                           (long long)2 * (C / 8) * HW, C, G, HW, 0, eps, act_silu, range);
     return lc_launch_status();
 }
 

@@ -52,9 +52,13 @@ __global__ __launch_bounds__(256) void down2_kernel(const float* __restrict__ x,
 // input rows and takes x[4l-1] / x[4l+4] from its neighbours with two DPP-class shuffles (the
 // ring wrap is a scalar load only at the two ends of the 256-column segment) -> 2 outputs per
 // lane, 4 vector loads instead of 32 scalar ones.  Same arithmetic order as the scalar form.
+// ostats != NULL (round 5): every item also leaves one GroupNorm statistics entry (pivot, n = 128, sum (v - pivot),
+// sum (v - pivot)^2) of the 128 values it stores, in the producer-statistics format with ONE channel per entry:
+// ostats[(b * C + c) * slots + (i * segs + sg)], slots = Ho * segs -- the GroupNorm behind a down-sampler then needs no
+// statistics pass (3 per C2 step, 12 per C3 step before).
 __global__ __launch_bounds__(256) void down2_vec_kernel(const float* __restrict__ x, long long x_bs,
                                                        float* __restrict__ y, long long y_bs, int C,
-                                                       int H, int W) {
+                                                       int H, int W, f32x4* __restrict__ ostats) {
     const int Ho = H / 2, Wo = W / 2;
     const int segs = W / 256;                                  // 256-column segments per row
     const long long n_items = (long long)C * Ho * segs;        // one wave each
@@ -89,6 +93,15 @@ __global__ __launch_bounds__(256) void down2_vec_kernel(const float* __restrict_
         }
         float2 o; o.x = acc0; o.y = acc1;
         *reinterpret_cast<float2*>(yb + ((long long)c * Ho + i) * Wo + w0 / 2) = o;
+        if (ostats) {                                          // (uniform)
+            const float piv = __builtin_amdgcn_readfirstlane(acc0);
+            const float d0 = acc0 - piv, d1 = acc1 - piv;
+            float s_ = d0 + d1, q_ = fmaf(d1, d1, d0 * d0);
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) { s_ += __shfl_xor(s_, sh, 64); q_ += __shfl_xor(q_, sh, 64); }
+            if (lane == 0)
+                ostats[((long long)b * C + c) * ((long long)Ho * segs) + ((long long)i * segs + sg)] = f32x4{piv, 128.0f, s_, q_};
+        }
     }
 }
 
@@ -134,9 +147,33 @@ __global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ x, l
 
 }  // namespace
 
+// statistics entries per channel the down-sampler leaves (0: this shape takes the scalar kernel, which leaves none)
+extern "C" int64_t lc_resample2x_stats_slots(int H, int W, int dir) {
+    if (dir >= 0 || H <= 0 || W <= 0 || (H & 1) || W % 256) return 0;
+    return (int64_t)(H / 2) * (W / 256);
+}
+
+static int resample2x(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H, int W, int dir,
+                      float* ostats, lc_stream_t s);
+
 extern "C" int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C,
                                  int H, int W, int dir, lc_stream_t s) {
+    return resample2x(x, x_bs, y, y_bs, B, C, H, W, dir, nullptr, s);
+}
+
+// ... the same, and (dir < 0, lc_resample2x_stats_slots(H, W, dir) > 0) one statistics entry per (sample, channel, slot) of
+// the OUTPUT into ostats[B, C, slots, 4] (lc_oct_stats with unit = 1).  LC_EUNSUP when the shape / alignment takes the
+// scalar kernel: the caller asks lc_resample2x_stats_slots first and falls back to lc_resample2x_fwd + a statistics pass.
+extern "C" int lc_resample2x_stats_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C,
+                                       int H, int W, int dir, float* ostats, lc_stream_t s) {
+    if (!ostats) return LC_EINVAL;
+    return resample2x(x, x_bs, y, y_bs, B, C, H, W, dir, ostats, s);
+}
+
+static int resample2x(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H, int W, int dir,
+                      float* ostats, lc_stream_t s) {
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return LC_EINVAL;
+    if (ostats && dir >= 0) return LC_EUNSUP;
     if (dir < 0) {
         if ((H & 1) || (W & 1)) return LC_EUNSUP;
         const long long total = (long long)C * (H / 2) * (W / 2);
@@ -147,9 +184,10 @@ extern "C" int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t
             const long long items = (long long)C * (H / 2) * (W / 256);
             int blocks = (int)((items + 3) / 4 > 16384 ? 16384 : (items + 3) / 4);
             hipLaunchKernelGGL(down2_vec_kernel, dim3(blocks, B), dim3(256), 0, lc_s(s), x,
-                               (long long)x_bs, y, (long long)y_bs, C, H, W);
+                               (long long)x_bs, y, (long long)y_bs, C, H, W, reinterpret_cast<f32x4*>(ostats));
             return lc_launch_status();
         }
+        if (ostats) return LC_EUNSUP;
         int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
         hipLaunchKernelGGL(down2_kernel, dim3(blocks, B), dim3(256), 0, lc_s(s), x, (long long)x_bs, y,
                            (long long)y_bs, C, H, W);

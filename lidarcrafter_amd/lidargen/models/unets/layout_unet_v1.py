@@ -35,12 +35,15 @@ class TimestepBlock(nn.Module):
 
 
 PAIR_STATS = os.environ.get("LC_GN_PAIR_STATS", "1") != "0"   # developer switch (A/B of the pair entries)
+QUAD_STATS = os.environ.get("LC_GN_QUAD_STATS", "1") != "0"   # ... of the pre-split kernel's quad entries (round 5)
 
 
 def _stats_unit(channels: int):
     """`emit_stats` of a conv whose output feeds a GroupNorm32: octet entries when the 32 groups are
-    whole octets (>= 256 channels), pair entries below (64 / 128 channels: 2 / 4 per group)."""
-    return True if (channels // 32) % 8 == 0 or not PAIR_STATS else 2
+    whole octets (>= 256 channels), quad entries at 128 channels (4 per group; the pre-split kernel writes quads, the
+    fp32-input kernels pairs), pair entries at 64 (2 per group)."""
+    cpg = channels // 32
+    return True if cpg % 8 == 0 or not PAIR_STATS else (4 if cpg % 4 == 0 and QUAD_STATS else 2)
 
 
 class ResBlock(TimestepBlock):

@@ -201,6 +201,8 @@ def set_conv_precision(mode: str) -> str:
 # tests/test_hip_parity.py::test_conv_statistics_entries_stress.)
 # LC_GN_PRODUCER_STATS=0 selects the statistics-pass route (one lc_groupnorm_stats launch per GroupNorm).
 PRODUCER_GN_STATS = _os.environ.get("LC_GN_PRODUCER_STATS", "1") != "0"
+# ... and the x2 down-sampler's per-channel entries (round 5); "0": a statistics pass behind every Resample(down=2)
+RESAMPLE_STATS = _os.environ.get("LC_RESAMPLE_STATS", "1") != "0"
 
 
 class _OctStatsHandle:
@@ -286,18 +288,27 @@ def _attach_stats(out: torch.Tensor, h: _OctStatsHandle) -> None:
 GN_TRACE = None   # developer aid: a collections.Counter of (shape, G, found) per statistics lookup
 
 
-def _find_stats(x: torch.Tensor, G: int, pairs_ok: bool = False):
-    """pairs_ok: the consumer can fold pair entries (the conv's fused input norm); the apply kernels
-    take octet entries only."""
-    r = _find_stats_impl(x, G, pairs_ok)
+def _find_stats(x: torch.Tensor, G: int, pairs_ok: bool = False, octet_groups: bool = False):
+    """Every consumer folds entries of any unit (8 / 4 / 2 / 1 channels per entry: round 5) as long as a group is a
+    whole number of entries.  octet_groups: the consumer is the pre-split apply pass (one block = one channel octet):
+    groups of whole octets, or 2 / 4 channels per group (one group per wave).  (pairs_ok: kept for callers; no effect.)"""
+    if octet_groups and (x.dim() != 4 or ((x.shape[1] // G) % 8 and x.shape[1] // G not in (2, 4))):
+        r = None
+    else:
+        r = _find_stats_impl(x, G, True)
     if GN_TRACE is not None:
-        GN_TRACE[(tuple(x.shape), G, r is not None)] += 1
+        why = ""
+        if r is None:        # what the tensor does carry (developer trace only)
+            own, c0 = _stats_owner(x) if x.dim() == 4 else (None, 0)
+            d = getattr(own, "_lc_gnstats", None) if own is not None else None
+            why = "none" if not d else ",".join(f"{k0 - c0}+{kc}/u{h.unit}" for (k0, kc), h in sorted(d.items()))
+        GN_TRACE[(tuple(x.shape), G, r is not None, why)] += 1
     return r
 
 
 def _find_stats_impl(x: torch.Tensor, G: int, pairs_ok: bool = False):
     """Handles covering all channels of x with at most two segments (each a whole number of
-    groups, groups whole octets), or None."""
+    groups, groups whole entries), or None."""
     if x.dim() != 4:
         return None
     own, c0 = _stats_owner(x)
@@ -312,7 +323,7 @@ def _find_stats_impl(x: torch.Tensor, G: int, pairs_ok: bool = False):
     cpg = C // G
 
     def usable(h):
-        return h.shape == shape and cpg % h.unit == 0 and (h.unit == 8 or pairs_ok)
+        return h.shape == shape and cpg % h.unit == 0
 
     shape = (x.shape[0], x.shape[2] * x.shape[3])
     h = d.get((c0, C))
@@ -923,7 +934,8 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
     input tile is staged (f16x2 kernels only).  ops.py:149-173 of the reference.
 
     emit_stats: True / 8 = the conv also leaves per-octet GroupNorm statistics of what it stores (2 =
-    per channel pair, for a consumer GroupNorm with 2 / 4 / 6 channels per group), attached to
+    per channel pair, for a consumer GroupNorm with 2 / 4 / 6 channels per group; 4 = per channel quad, for
+    4 / 12 per group: the pre-split kernel writes quads, the fp32-input kernels the finer pairs), attached to
     the output tensor object; a following `groupnorm` / `groupnorm_stats` of that tensor (or of a
     concat buffer whose halves both carry them) then skips its statistics pass.  Every wrapper of
     this module that writes into an `out=` tensor forgets the statistics of what it overwrites;
@@ -981,7 +993,8 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
                     raise ValueError("gn_coeffs must be contiguous [B, Cpad, 4]")
                 cpad = gn_coeffs.shape[1]
             sbuf, slots = None, 0
-            unit = 2 if (emit_stats is not True and int(emit_stats) == 2) else 8
+            # (4 = quad entries: the pre-split kernel's; the deferred epilogue of these kernels writes the finer pairs)
+            unit = 2 if (emit_stats is not True and int(emit_stats) in (2, 4)) else 8
             if emit_stats and PRODUCER_GN_STATS and (unit == 8 or ks == 3):   # pair entries: 3x3 kernels only
                 slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, Ci, Co, H, W, ks, int(tile_cfg)))
                 if slots > 0:
@@ -1043,18 +1056,19 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                 rd=4.0 * (B * Ci * H * W + Co * Ci * 9 + (B * Co * H * W if res is not None else 0)),
                 wr=4.0 * B * Co * H * W):
         sbuf, slots = None, 0
-        # (pair entries -- emit_stats == 2 -- come from the fp32-input kernel's deferred epilogue only)
-        want_stats = emit_stats and (emit_stats is True or int(emit_stats) == 8) and PRODUCER_GN_STATS and \
-            Co % 8 == 0
+        # octet or quad entries (pair entries -- emit_stats == 2 -- come from the fp32-input kernel's deferred epilogue
+        # only; quads: this kernel's epilogue, not the split-K reduction)
+        unit = 8 if emit_stats is True else int(emit_stats or 0)
+        want_stats = unit in (8, 4) and PRODUCER_GN_STATS and Co % 8 == 0
         if ks >= 2:
             # small grid: ksplit blocks per tile over disjoint K ranges + one deterministic reduce
             part = torch.empty((ks, B, Co, H, W), device=dev, dtype=_F32)
             check(_conv_lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
                                                     None, None, 0, None, 0, B, Ci, Co, H, W, 1.0, sk_cfg,
-                                                    None, part.data_ptr(), ks,
+                                                    None, 8, part.data_ptr(), ks,
                                                     packed.wmeta.data_ptr(), packed.range_ptr(dev),
                                                     _stream()), "lc_conv2d_ring_f16x2_ps_fwd")
-            if want_stats:
+            if want_stats and unit == 8:
                 slots = int(lib().lc_splitk_stats_slots(H, W))
                 sbuf = torch.empty((B, Co // 8, slots, 4), device=dev, dtype=_F32)
             check(lib().lc_splitk_reduce(part.data_ptr(), ks, _p(bias), _p(res), r_bs, out.data_ptr(),
@@ -1065,15 +1079,16 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
                 slots = int(lib().lc_conv2d_ring_f16x2_stats_slots(B, max(Ci, 24), Co, H, W, 3,
                                                                    int(tile_cfg)))
                 if slots > 0:
-                    sbuf = torch.empty((B, Co // 8, slots, 4), device=dev, dtype=_F32)
+                    sbuf = torch.empty((B, Co // unit, slots, 4), device=dev, dtype=_F32)
             check(_conv_lib().lc_conv2d_ring_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(),
                                                     _p(bias), _p(res), r_bs, out.data_ptr(), y_bs, B,
                                                     Ci, Co, H, W, float(out_scale), int(tile_cfg),
-                                                    _p(sbuf), None, 0, packed.wmeta.data_ptr(),
+                                                    _p(sbuf), unit if sbuf is not None else 8, None, 0,
+                                                    packed.wmeta.data_ptr(),
                                                     packed.range_ptr(dev), _stream()),
                   "lc_conv2d_ring_f16x2_ps_fwd")
         if sbuf is not None:
-            _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H * W)))
+            _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, H * W), unit))
     return out
 
 
@@ -1183,7 +1198,7 @@ def _groupnorm_split(x, x_bs, G, eps, gamma, beta, scale, shift, act_silu, packe
     buf = torch.empty((units, 8), device=x.device, dtype=torch.float16)
     rng_ptr = packed.range_ptr(x.device)
     st = _stream()
-    hs = _find_stats(x, G)
+    hs = _find_stats(x, G, octet_groups=True)
     if hs is not None:
         keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots, h.unit) for h in hs]
         with _Timed("groupnorm", 8.0 * B * C * H * W):
@@ -1300,9 +1315,21 @@ def resample2x(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None) ->
     if tuple(out.shape) != shape:
         raise ValueError("resample: out shape mismatch")
     _drop_stats(out)
+    # the down-sampler leaves per-channel GroupNorm statistics of what it stores where its vector kernel runs (W % 256 == 0,
+    # aligned rows): the GroupNorm behind it then takes no statistics pass
+    slots = 0
+    if not up and PRODUCER_GN_STATS and RESAMPLE_STATS and x.data_ptr() % 16 == 0 and x_bs % 4 == 0 and y_bs % 2 == 0 \
+            and out.data_ptr() % 8 == 0:
+        slots = int(lib().lc_resample2x_stats_slots(H, W, -1))
     with _Timed("resample", 4.0 * B * C * H * W * (5.0 if up else 1.25)):
-        check(lib().lc_resample2x_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W,
-                                      1 if up else -1, _stream()), "lc_resample2x_fwd")
+        if slots > 0:
+            sbuf = torch.empty((B, C, slots, 4), device=x.device, dtype=_F32)
+            check(lib().lc_resample2x_stats_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W, -1,
+                                                sbuf.data_ptr(), _stream()), "lc_resample2x_stats_fwd")
+            _attach_stats(out, _OctStatsHandle(sbuf, C, slots, (B, (H // 2) * (W // 2)), 1))
+        else:
+            check(lib().lc_resample2x_fwd(x.data_ptr(), x_bs, out.data_ptr(), y_bs, B, C, H, W,
+                                          1 if up else -1, _stream()), "lc_resample2x_fwd")
     return out
 
 

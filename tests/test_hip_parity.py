@@ -273,8 +273,8 @@ def test_conv_fused_groupnorm_from_producer_stats(dev, B, C, H, W, G, ks, cfg):
 def test_conv_fused_groupnorm_from_pair_stats(dev, B, C, H, W, cfg):
     """GroupNorm32 at 64 / 128 channels has 2 / 4 channels per group: the producers leave one entry
     per channel PAIR (emit_stats=2) and the consumer conv folds those -- same result as the two-pass
-    route; single producer (2 per group), concat of two producers with different tiles (4 per group),
-    and the bookkeeping: the apply kernels do not take pair entries."""
+    route; single producer (2 per group), concat of two producers with different tiles (4 per group);
+    the apply kernel folds the same pair entries (round 5: entries of any unit that divides a group)."""
     from lidarcrafter_amd import ops as K
 
     x = seeded_randn(B, 32, H, W, seed=291).to(dev)
@@ -286,7 +286,9 @@ def test_conv_fused_groupnorm_from_pair_stats(dev, B, C, H, W, cfg):
     K.conv2d_ring(x, K.PackedConv(), w1, bias1, res=res, out=cat[:, :C], tile_cfg=23 if H % 4 == 0 else 25,
                   emit_stats=2)
     K.conv2d_ring(x, K.PackedConv(), w2, None, out=cat[:, C:], tile_cfg=13, emit_stats=2)
-    assert K._find_stats(cat, 32) is None and K._find_stats(cat, 32, pairs_ok=True) is not None
+    assert K._find_stats(cat, 32) is not None and K._find_stats(cat, 32, octet_groups=True) is not None
+    assert K._find_stats(cat, 16, octet_groups=True) is not None      # (whole-octet groups from pair entries)
+    assert K._find_stats(cat, 128) is None           # (one channel per group: half a pair entry)
     for src, Ci in ((cat[:, :C], C), (cat, 2 * C)):
         wc = (seeded_randn(64, Ci, 3, 3, seed=295) / (Ci * 9) ** 0.5).to(dev)
         ga, be = (1 + 0.1 * seeded_randn(Ci, seed=296)).to(dev), (0.1 * seeded_randn(Ci, seed=297)).to(dev)
@@ -299,9 +301,17 @@ def test_conv_fused_groupnorm_from_pair_stats(dev, B, C, H, W, cfg):
         assert st_ref._struct.partials is not None
         ref = K.conv2d_ring(ref_in, K.PackedConv(), wc, None, tile_cfg=cfg, gn_coeffs=st_ref, gn_silu=True)
         assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
-    # the apply kernels fall back to their own statistics pass for such a tensor (no error)
+    # the apply kernel from the same pair entries against its own statistics pass
     y = K.groupnorm(cat, 32, 1e-6, act_silu=True)
-    assert rel_l2(y, K.groupnorm(cat.clone(), 32, 1e-6, act_silu=True)) == 0.0
+    assert rel_l2(y, K.groupnorm(cat.clone(), 32, 1e-6, act_silu=True)) < 2e-6
+    # ... and the pre-split apply pass: 4 channels per group over the concat (one group per wave), 2 over its first half
+    for src, Ci in ((cat[:, :C], C), (cat, 2 * C)):
+        wc = (seeded_randn(64, Ci, 3, 3, seed=295) / (Ci * 9) ** 0.5).to(dev)
+        pk1, pk2 = K.PackedConv(), K.PackedConv()
+        s1 = K.groupnorm(src, 32, 1e-6, act_silu=True, split_for=pk1)
+        s2 = K.groupnorm(src.clone(), 32, 1e-6, act_silu=True, split_for=pk2)
+        assert isinstance(s1, K.SplitAct) and isinstance(s2, K.SplitAct)
+        assert rel_l2(K.conv2d_ring(s1, pk1, wc, None), K.conv2d_ring(s2, pk2, wc, None)) < 2e-6
 
 
 @pytest.mark.parametrize("unit", [8, 2])
@@ -498,6 +508,44 @@ def test_resample(dev, B, C, H, W, golden):
         g = golden("ops")
         assert rel_l2(K.resample2x(xd, up=False), T(g["down_y"])) < 1e-6
         assert rel_l2(K.resample2x(xd, up=True), T(g["up_y"])) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,H,W,G", [(2, 128, 8, 512, 8), (1, 64, 32, 1024, 8), (2, 32, 4, 256, 4), (1, 128, 16, 768, 32)])
+def test_resample_down_statistics_feed_groupnorm(dev, B, C, H, W, G):
+    """The x2 down-sampler's per-channel statistics entries (resample.hip, where its vector kernel runs): every entry
+    recomputed from the plane the same launch stored, and each GroupNorm consumer -- apply, apply + fp16 split for
+    the pre-split convolutions, the convolution's fused input norm -- fed from them against the same consumer behind a
+    statistics pass (<= 2e-6) and against the oracle."""
+    from lidarcrafter_amd import ops as K
+    from oracle import denoiser as D
+
+    x = (seeded_randn(B, C, H, W, seed=77) * 1.2 + 0.35)
+    y = K.resample2x(x.to(dev), up=False)
+    h = y._lc_gnstats[(0, C)]
+    assert h.unit == 1 and h.slots == (H // 2) * (W // 2 // 128) and tuple(h.buf.shape) == (B, C, h.slots, 4)
+    e = h.buf.double()
+    rv = y.double().view(B, C, H // 2, W // 2 // 128, 128).reshape(B, C, h.slots, 128)
+    pv, n, s_, q = e[..., 0], e[..., 1], e[..., 2], e[..., 3]
+    assert bool((n == 128.0).all())
+    assert float(((pv * n + s_) - rv.sum(-1)).abs().max()) < 2e-3
+    rq = (rv * rv).sum(-1)
+    assert float((((q + 2 * pv * s_ + pv * pv * n) - rq).abs() / rq.clamp(min=1.0)).max()) < 1e-4
+
+    ga, be = (1 + 0.1 * seeded_randn(C, seed=78)).to(dev), (0.1 * seeded_randn(C, seed=79)).to(dev)
+    y2 = y.clone()                                   # (no entries follow a clone: the statistics-pass route)
+    assert not getattr(y2, "_lc_gnstats", None)
+    ref = D.group_norm(D.resample_down2(x), G, ga.cpu(), be.cpu(), 1e-6)
+    a1, a2 = K.groupnorm(y, G, 1e-6, ga, be), K.groupnorm(y2, G, 1e-6, ga, be)
+    assert rel_l2(a1, a2) < 2e-6 and rel_l2(a1, ref) < 2e-6
+    w = (seeded_randn(64, C, 3, 3, seed=80) / (C * 9) ** 0.5).to(dev)
+    c1 = K.conv2d_ring(y, K.PackedConv(), w, None, gn_coeffs=K.groupnorm_stats(y, G, 1e-6, ga, be), gn_silu=True)
+    c2 = K.conv2d_ring(y2, K.PackedConv(), w, None, gn_coeffs=K.groupnorm_stats(y2, G, 1e-6, ga, be), gn_silu=True)
+    assert rel_l2(c1, c2) < 2e-6
+    if (C // G) % 8 == 0:
+        pk1, pk2 = K.PackedConv(), K.PackedConv()
+        s1 = K.conv2d_ring(K.groupnorm(y, G, 1e-6, ga, be, act_silu=True, split_for=pk1), pk1, w, None)
+        s2 = K.conv2d_ring(K.groupnorm(y2, G, 1e-6, ga, be, act_silu=True, split_for=pk2), pk2, w, None)
+        assert rel_l2(s1, s2) < 2e-6 and rel_l2(s1, c1) < 2e-6
 
 
 # ------------------------------------------------------------------------------------- dense

@@ -50,8 +50,12 @@ def test_groupnorm_split_matches_fp32_route(dev, B, C, H, W, G, mode, route):
         if W % 32 or H % 2:
             pytest.skip("the producer conv needs a pipelined tile shape")
         w = (seeded_randn(C, C, 3, 3, seed=6) / (3 * C ** 0.5)).to(dev)
-        x = K.conv2d_ring(x, K.PackedConv(), w, emit_stats=True)
-        assert (K._find_stats(x, G) is not None) == ((C // G) % 8 == 0)   # narrower groups: statistics pass
+        # octet entries for groups of whole octets, else what the models ask for (layout_unet_v1._stats_unit): quads
+        # (this fp32-input producer writes the finer pairs) at 4 / 12 per group, pairs below.  The pre-split apply pass
+        # folds them for whole-octet groups and for 2 / 4 channels per group (round 5); 1 / 3 / 6 / 12: statistics pass
+        cpg = C // G
+        x = K.conv2d_ring(x, K.PackedConv(), w, emit_stats=True if cpg % 8 == 0 else (4 if cpg % 4 == 0 else 2))
+        assert (K._find_stats(x, G, octet_groups=True) is not None) == (cpg % 8 == 0 or cpg in (2, 4))
     pk = K.PackedConv("consumer")
     ref = K.groupnorm(x.clone(), G, 1e-6, act_silu=True, **kw)
     sa = K.groupnorm(x, G, 1e-6, act_silu=True, split_for=pk, **kw)
@@ -92,6 +96,32 @@ def test_conv_presplit_vs_oracle(dev, B, Ci, Co, H, W, cfg):
             g1 = K.groupnorm(y2, 8, 1e-6)
             g2 = K.groupnorm(y.clone(), 8, 1e-6)
             assert rel_l2(g1, g2) < 2e-6
+        # quad entries (round 5; not from the split-K reduction): every entry against the stored output, then the
+        # consumers at 4 channels per group -- apply, pre-split apply (one group per wave), a conv's fused input norm
+        y4 = K.conv2d_ring(sa, pk, w.to(dev), b.to(dev), res=res.to(dev), out_scale=0.7071,
+                           tile_cfg=cfg, emit_stats=4)
+        assert torch.equal(y4, y)
+        d = getattr(y4, "_lc_gnstats", None)
+        if cfg != 0 or B * H * W >= 4096:
+            assert d, "no quad entries from the pre-split kernel"
+        if d and Co % 16 == 0:
+            h = d[(0, Co)]
+            assert h.unit == 4 and tuple(h.buf.shape) == (B, Co // 4, h.slots, 4)
+            e = h.buf.double()
+            n, tot = e[..., 1], e[..., 0] * e[..., 1] + e[..., 2]
+            assert bool((n.sum(-1) == 4.0 * H * W).all())
+            assert float((tot.sum(-1) - y.double().view(B, Co // 4, -1).sum(-1)).abs().max()) < 2e-3 * (H * W) ** 0.5
+            G4 = Co // 4
+            yc = y.clone()
+            assert rel_l2(K.groupnorm(y4, G4, 1e-6, act_silu=True), K.groupnorm(yc, G4, 1e-6, act_silu=True)) < 2e-6
+            pk2 = K.PackedConv("next")
+            s1 = K.groupnorm(y4, G4, 1e-6, act_silu=True, split_for=pk2)
+            assert isinstance(s1, K.SplitAct)
+            assert rel_l2(decode(s1), K.groupnorm(yc, G4, 1e-6, act_silu=True)) < 4e-7
+            w2 = (seeded_randn(64, Co, 3, 3, seed=17) / (Co * 9) ** 0.5).to(dev)
+            c1 = K.conv2d_ring(y4, K.PackedConv(), w2, None, gn_coeffs=K.groupnorm_stats(y4, G4, 1e-6), gn_silu=True)
+            c2 = K.conv2d_ring(yc, K.PackedConv(), w2, None, gn_coeffs=K.groupnorm_stats(yc, G4, 1e-6), gn_silu=True)
+            assert rel_l2(c1, c2) < 2e-6
 
 
 def test_presplit_belongs_to_one_layer(dev):
