@@ -17,7 +17,10 @@ static inline int lc_launch_status() {
     return e == hipSuccess ? LC_OK : (int)e;
 }
 
-__device__ __forceinline__ float lc_silu(float v) { return v / (1.0f + __expf(-v)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp), as the convolutions' fused input norm computes it
+// (conv_f16x2_common.h gn_act).  Round 5: the IEEE division here was ~10 of the ~24 VALU instructions per element of the
+// GroupNorm apply passes, which are VALU-bound, not HBM-bound (profiles/r05_level0.txt section 7).
+__device__ __forceinline__ float lc_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ double lc_wave_sum(double v) {
 #pragma unroll

@@ -948,9 +948,37 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
         }
     float res_r[C::TCO_][C::TPX_][16];
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+#ifndef LC_PS_BUFEPI
+#define LC_PS_BUFEPI 1   // 1: residual loads / output stores as raw buffer operations (no branch, no 64-bit address per
+#endif                   //    value: round 5); 0: predicated global loads / stores (developer A/B)
+    // Buffer form: descriptors of sample b (residual: no records when there is none -> zeros); per pixel column j ONE
+    // byte offset of (channel co_wave, pixel), the value's channel rides in the scalar offset; an out-of-image pixel
+    // or a channel past Co is an out-of-range offset.  (Host side: Co * H * W * 4 < 2^31.)
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rs_yb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.y + (long long)b * a.y_bs), 0, (unsigned)a.Co * HW4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc((void*)rb, 0, rb ? (unsigned)a.Co * HW4 : 0u,
+                                                                          0x00020000);
+    auto px_off = [&](int j) -> unsigned {       // byte offset of (co_wave, pixel j of this wave's tile), or OOB
+        const int t = wpx * C::TPX_ + j;
+        const int tr = t / C::TPR, tc = t - tr * C::TPR;
+        const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
+        return (gh < H && gw < W) ? (unsigned)(co_wave * HW + gh * W + gw) * 4u : OOB;
+    };
     auto prefetch_res = [&]() {
 #pragma unroll
         for (int j = 0; j < C::TPX_; ++j) {
+#if LC_PS_BUFEPI
+            const unsigned vo = px_off(j);
+#pragma unroll
+            for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cor = i * 32 + (r & 3) + 8 * (r >> 2);
+                    res_r[i][j][r] = (LC_PS_ABL & 16) ? 0.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rs_rb, co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, 0));
+                }
+#else
             const int t = wpx * C::TPX_ + j;
             const int tr = t / C::TPR, tc = t - tr * C::TPR;
             const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
@@ -963,6 +991,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
                     res_r[i][j][r] = (rb && pok && co < a.Co && !(LC_PS_ABL & 16)) ? rb[(long long)co * HW + poff] : 0.0f;
                 }
+#endif
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1012,6 +1041,8 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
             const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
             const bool pok = gh < H && gw < W;
             const long long poff = (long long)gh * W + gw;
+            const unsigned vo_j = pok ? (unsigned)(co_wave * HW + (int)poff) * 4u : OOB;
+            (void)vo_j; (void)poff;
             if constexpr (EMIT_STATS) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
 #pragma unroll
             for (int i = 0; i < C::TCO_; ++i) {
@@ -1020,7 +1051,13 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
                     const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
                                     a.out_scale;
+#if LC_PS_BUFEPI
+                    if (!(LC_PS_ABL & 16))
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_yb, co < a.Co ? vo_j : OOB,
+                                                              (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * HW4, LC_DEF_AUX);
+#else
                     if (pok && co < a.Co && !(LC_PS_ABL & 16)) epi_store(&yb[(long long)co * HW + poff], v);
+#endif
                     if constexpr (EMIT_STATS && !(LC_EMIT_ABL & 1)) {
                         const int m = r >> 2;
                         if (j == 0 && (r & 3) == 0) {
@@ -1591,6 +1628,7 @@ extern "C" int lc_conv2d_ring_f16x2_ps_fwd(const void* x_split, const void* wp_h
     if (Ci % 16) return LC_EUNSUP;
     if (splitk_part && (ksplit < 2 || ksplit > Ci / 16)) return LC_EINVAL;
     if ((long long)H * W >= (1 << 24) || (long long)2 * (Ci / 8) * H * W * 16 >= (1ll << 31)) return LC_EUNSUP;
+    if ((long long)Co * H * W * 4 >= (1ll << 31)) return LC_EUNSUP;       // 32-bit offsets into one output sample
     ConvArgsH a;
     a.x = nullptr; a.wh = (const half8*)wp_hi; a.wl = (const half8*)wp_lo; a.bias = bias; a.res = res;
     a.y = y; a.x_bs = 0; a.res_bs = res_bs; a.y_bs = y_bs;

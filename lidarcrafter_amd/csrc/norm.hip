@@ -557,13 +557,17 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) { mu[k] = (float)(P0 + m); rstd[k] = (float)(1.0 / sqrt(var + (double)eps)); }
     }
-    float ga[8], be[8], sc[8], sf[8];
+    // per channel: y = (x - mean) * A + Bc with A = rstd * gamma * (1 + scale), Bc = beta * (1 + scale) + shift -- the
+    // form (and rounding order) of the convolutions' fused input norm (conv_f16x2_common.h gn_act)
+    float cA[8], cB[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = c0 + k;
-        ga[k] = gamma ? gamma[c] : 1.0f; be[k] = beta ? beta[c] : 0.0f;
-        sc[k] = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
-        sf[k] = shift ? shift[b * ss_bs + c] : 0.0f;
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+        const float sf = shift ? shift[b * ss_bs + c] : 0.0f;
+        cA[k] = rstd[k] * ga * sc;
+        cB[k] = be * sc + sf;
     }
     const float xs = range->x_scale;
     const float seen = range->amax_scaled;
@@ -574,9 +578,7 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     auto one = [&](const float (&v)[8], half8_t& h8, half8_t& l8) {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-            float t0 = (v[k] - mu[k]) * rstd[k], t1 = (v[k + 1] - mu[k + 1]) * rstd[k + 1];
-            t0 = t0 * ga[k] + be[k];         t1 = t1 * ga[k + 1] + be[k + 1];
-            t0 = t0 * sc[k] + sf[k];         t1 = t1 * sc[k + 1] + sf[k + 1];
+            float t0 = fmaf(v[k] - mu[k], cA[k], cB[k]), t1 = fmaf(v[k + 1] - mu[k + 1], cA[k + 1], cB[k + 1]);
             if (act) { t0 = lc_silu(t0); t1 = lc_silu(t1); }
             const float s0 = t0 * xs, s1 = t1 * xs;
             am = fmaxf(am, fmaxf(fabsf(s0), fabsf(s1)));
@@ -589,13 +591,9 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
         }
     };
     if (vec) {
-        // four consecutive pixels per thread: 8 float4 channel loads, 2 x 4 contiguous 16-byte stores
-        for (long long p = lo + threadIdx.x * 4; p < hi; p += 1024) {
-            f32x4 c4[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                c4[k] = p == lo + threadIdx.x * 4 ? c4_first[k]
-                                                  : *reinterpret_cast<const f32x4*>(xp + (long long)k * HW + p);
+        // four consecutive pixels per thread: 8 float4 channel loads, 2 x 4 contiguous 16-byte stores; the first quad is
+        // the one issued ahead of the fold (peeled: a select per load inside the loop compiled to 8 branches)
+        auto quad = [&](const f32x4 (&c4)[8], long long p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[8];
@@ -606,6 +604,14 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
                 yh[p + q] = h8;
                 yl[p + q] = l8;
             }
+        };
+        long long p = lo + threadIdx.x * 4;
+        if (p < hi) quad(c4_first, p);
+        for (p += 1024; p < hi; p += 1024) {
+            f32x4 c4[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c4[k] = *reinterpret_cast<const f32x4*>(xp + (long long)k * HW + p);
+            quad(c4, p);
         }
     } else {
         for (long long p = lo + threadIdx.x; p < hi; p += 256) {
