@@ -218,26 +218,54 @@ __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void con
     }
 
     publish_amax(a.range, am, amax_seen);
-    float* yb = a.y + (long long)b * a.y_bs;
+    // Epilogue on raw buffer operations (round 5): bias and residual loads of a pixel column all go out first, then the
+    // values are finished and stored -- no branch, no 64-bit address per value.  (First form: per value a predicated block
+    // "bias load, wait, residual load, wait, store" -- 2 x 16 serial memory round trips per thread; the projections of the
+    // attention blocks spent most of their 25 us there.)  Out-of-image pixels, channels past Co, "no bias" and "no
+    // residual" are out-of-range offsets / empty descriptors (loads return 0).  Same arithmetic order as before.
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned HW4 = (unsigned)HW * 4u;
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long long)b * a.y_bs), 0,
+                                                                         (unsigned)a.Co * HW4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rb, 0, rb ? (unsigned)a.Co * HW4 : 0u,
+                                                                         0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0,
+                                                                         a.bias ? (unsigned)a.Co * 4u : 0u, 0x00020000);
+    const int co_wave = co0 + wco * C::TCO_ * 32 + 4 * kh;          // (per lane half)
+    float bias_r[C::TCO_][16];
+#pragma unroll
+    for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
+            bias_r[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (unsigned)co * 4u, 0, 0));
+        }
 #pragma unroll
     for (int j = 0; j < C::TPX_; ++j) {
         const int t = wpx * C::TPX_ + j;
         const int tr = t / C::TPR, tc = t - tr * C::TPR;
         const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-        const bool pok = gh < H && gw < W;
-        const long long poff = (long long)gh * W + gw;
+        const unsigned vo = (gh < H && gw < W) ? (unsigned)(co_wave * (int)HW + gh * W + gw) * 4u : OOB;
+        float res_r[C::TCO_][16];
+#pragma unroll
+        for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cor = i * 32 + (r & 3) + 8 * (r >> 2);
+                res_r[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_r, co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, 0));
+            }
 #pragma unroll
         for (int i = 0; i < C::TCO_; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wco * C::TCO_ + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (pok && co < a.Co) {
-                    float v = acc[i][j][r] * out_unscale;
-                    if (a.bias) v += a.bias[co];
-                    if (rb) v += rb[(long long)co * HW + poff];
-                    yb[(long long)co * HW + poff] = v * a.out_scale;
-                }
+                const int cor = i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * out_unscale;
+                v += bias_r[i][r];
+                v += res_r[i][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v * a.out_scale), rs_y,
+                                                      co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, 0);
             }
         }
     }
