@@ -34,7 +34,7 @@ namespace {
 __device__ unsigned long long lc_dbg[32];
 #endif
 
-template <class C, bool WIDE = false>
+template <class C, bool WIDE = false, bool EMIT = false>   // EMIT: octet statistics entries of the output (1x1 launches, round 5)
 __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void conv_f16x2_kernel(ConvArgsH a) {
     constexpr int HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
     constexpr int XR = C::XR, XW = C::XW;
@@ -241,12 +241,16 @@ __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void con
             const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
             bias_r[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, (unsigned)co * 4u, 0, 0));
         }
+    float st_p[C::TCO_][4], st_s[C::TCO_][4], st_q[C::TCO_][4];
+    int nvalid = 0;
 #pragma unroll
     for (int j = 0; j < C::TPX_; ++j) {
         const int t = wpx * C::TPX_ + j;
         const int tr = t / C::TPR, tc = t - tr * C::TPR;
         const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-        const unsigned vo = (gh < H && gw < W) ? (unsigned)(co_wave * (int)HW + gh * W + gw) * 4u : OOB;
+        const bool pok = gh < H && gw < W;
+        const unsigned vo = pok ? (unsigned)(co_wave * (int)HW + gh * W + gw) * 4u : OOB;
+        if constexpr (EMIT) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
         float res_r[C::TCO_][16];
 #pragma unroll
         for (int i = 0; i < C::TCO_; ++i)
@@ -264,10 +268,40 @@ __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void con
                 float v = acc[i][j][r] * out_unscale;
                 v += bias_r[i][r];
                 v += res_r[i][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v * a.out_scale), rs_y,
+                v *= a.out_scale;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y,
                                                       co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, 0);
+                if constexpr (EMIT) {      // per channel octet (m; both lane halves) of this wave's pixels, as the pipelined kernels
+                    const int m = r >> 2;
+                    if (j == 0 && (r & 3) == 0) {
+                        st_p[i][m] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pok ? v : 0.0f), 0));
+                        st_s[i][m] = 0.f; st_q[i][m] = 0.f;
+                    }
+                    const float d = pok ? v - st_p[i][m] : 0.0f;
+                    st_s[i][m] += d;
+                    st_q[i][m] = fmaf(d, d, st_q[i][m]);
+                }
             }
         }
+    }
+    if constexpr (EMIT) {
+        const int slot = (th_i * a.tiles_w + tw_i) * C::WPX_ + wpx;
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.ostats + (long long)b * (a.Co >> 3) * a.oslots), 0, (unsigned)(a.Co >> 3) * (unsigned)a.oslots * 16u,
+            0x00020000);
+        const float nv = (float)(8 * nvalid);
+        const int co_blk = co0 + wco * C::TCO_ * 32;
+#pragma unroll
+        for (int i = 0; i < C::TCO_; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int co_oct = co_blk + i * 32 + 8 * m;
+                const float sf = wave_sum_to_lane63(st_s[i][m]), qf = wave_sum_to_lane63(st_q[i][m]);
+                const unsigned vo = (lane >= 60 && co_oct < a.Co)
+                                        ? ((unsigned)(co_oct >> 3) * (unsigned)a.oslots + (unsigned)slot) * 16u + 4u * (lane & 3)
+                                        : OOB;
+                store_entry_4lanes(rs_o, st_p[i][m], nv, sf, qf, vo);
+            }
     }
 }
 
@@ -1203,10 +1237,19 @@ int launch_h(ConvArgsH a, hipStream_t st) {
     a.tiles_w = (a.W + C::TW_ - 1) / C::TW_;
     dim3 grid(a.B * a.tiles_h * a.tiles_w, (a.Co + C::BN - 1) / C::BN);
     if constexpr (C::NTAP == 1) {
-        if ((long long)grid.x * grid.y <= 512) {
+        const bool wide = (long long)grid.x * grid.y <= 512;
+        if (a.ostats) {                        // octet entries (1x1 launches only: lc_conv2d_ring_f16x2_stats_slots)
+            if (a.ounit != 8) return LC_EUNSUP;
+            if (wide) hipLaunchKernelGGL((conv_f16x2_kernel<C, true, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_f16x2_kernel<C, false, true>), grid, dim3(256), 0, st, a);
+            return lc_launch_status();
+        }
+        if (wide) {
             hipLaunchKernelGGL((conv_f16x2_kernel<C, true>), grid, dim3(256), 0, st, a);
             return lc_launch_status();
         }
+    } else if (a.ostats) {
+        return LC_EUNSUP;
     }
     hipLaunchKernelGGL((conv_f16x2_kernel<C, false>), grid, dim3(256), 0, st, a);
     return lc_launch_status();
@@ -1276,9 +1319,15 @@ int dispatch_h(int cfg, const ConvArgsH& a, hipStream_t st) {
 
 // wave tiles per (sample, channel) plane of the pipelined configurations = statistics entries per
 // channel octet; 0 for the configurations of the other kernel (they emit no statistics)
-int pipe_stat_slots(int cfg, int H, int W) {
+int pipe_stat_slots(int cfg, int H, int W, int ks = 3) {
     int th, tw, wpx;
     switch (cfg) {
+        // the non-pipelined kernel writes entries for 1x1 launches only (round 5): its tiles 1 ... 5
+        case 1: if (ks != 1) return 0; th = 2; tw = 64; wpx = 2; break;
+        case 2: if (ks != 1) return 0; th = 4; tw = 64; wpx = 4; break;
+        case 3: if (ks != 1) return 0; th = 2; tw = 32; wpx = 2; break;
+        case 4: if (ks != 1) return 0; th = 4; tw = 32; wpx = 2; break;
+        case 5: if (ks != 1) return 0; th = 2; tw = 64; wpx = 4; break;
         case 12: th = 4; tw = 64; wpx = 4; break;
         case 13: th = 2; tw = 32; wpx = 2; break;
         case 15: th = 2; tw = 64; wpx = 4; break;
@@ -1617,7 +1666,7 @@ extern "C" int lc_conv2d_ring_f16x2_fwd(const float* x, int64_t x_bs, const void
     a.ostats = nullptr; a.oslots = 0; a.ounit = 8;
     if (gn_ostats_out) {
         if (gn_ostats_unit != 8 && gn_ostats_unit != 2) return LC_EINVAL;
-        a.oslots = pipe_stat_slots(tile_cfg, H, W);
+        a.oslots = pipe_stat_slots(tile_cfg, H, W, ks);
         if (a.oslots <= 0 || Co % 8) return LC_EUNSUP;     // ask lc_conv2d_ring_f16x2_stats_slots first
         a.ostats = reinterpret_cast<f32x4*>(gn_ostats_out);
         a.ounit = gn_ostats_unit;
@@ -1640,7 +1689,7 @@ extern "C" int64_t lc_conv2d_ring_f16x2_stats_slots(int B, int Ci, int Co, int H
     if (tile_cfg >= 100) tile_cfg %= 100;
     if (ks == 1 && ((long long)H * W) % 128 == 0) { H = (int)(((long long)H * W) / 64); W = 64; }
     if (tile_cfg == 0) tile_cfg = auto_cfg_h(B, Ci, Co, H, W, ks);
-    return pipe_stat_slots(tile_cfg, H, W);
+    return pipe_stat_slots(tile_cfg, H, W, ks);
 }
 
 // Pre-split input: see conv_f16x2_ps_kernel.  3x3 ring convolution only.

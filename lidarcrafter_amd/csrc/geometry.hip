@@ -12,28 +12,57 @@ namespace {
 // python float is a float64 scalar and promotes the expression; oracle/lidar.py "native_cr");
 // false: all-float32, the reference under its pinned numpy 1.23.5 (oracle "f32").
 template <bool ELEV64>
-__device__ __forceinline__ void cell_of(float x, float y, float z, int H, int W, double h_up64,
-                                        double h_down64, float& depth, int& gh, int& gw) {
-    depth = sqrtf((x * x + y * y) + z * z);
-    const float t = z / (depth + 1e-6f);
-    const float a32 = (float)asin((double)t);
+__device__ __forceinline__ int row_of(float a32, int H, double h_up64, double h_down64) {
     if constexpr (ELEV64) {
         const double elev = (double)a32 + fabs(h_down64);
         double fh = 1.0 - elev / (h_up64 - h_down64);
         fh = floor(fh * (double)H);
-        gh = (int)fmin(fmax(fh, 0.0), (double)(H - 1));
+        return (int)fmin(fmax(fh, 0.0), (double)(H - 1));
     } else {
         const float h_up = (float)h_up64, h_down = (float)h_down64;
         const float elev = a32 + fabsf(h_down);
         float fh = 1.0f - elev / (h_up - h_down);
         fh = floorf(fh * (float)H);
-        gh = (int)fminf(fmaxf(fh, 0.f), (float)(H - 1));
+        return (int)fminf(fmaxf(fh, 0.f), (float)(H - 1));
     }
-    const float az = -(float)atan2((double)y, (double)x);
-    float fw = (az / 3.14159274101257324f + 1.0f) / 2.0f;
+}
+// azimuth -> (v before np.mod, column of v): v = (-atan2 / pi32 + 1) / 2
+__device__ __forceinline__ float col_v(float atan32) { return (-atan32 / 3.14159274101257324f + 1.0f) / 2.0f; }
+__device__ __forceinline__ int col_of(float fw, int W) {
     fw = fw - floorf(fw);              // np.mod(v, 1) for v in [0, 1]
     fw = floorf(fw * (float)W);
-    gw = (int)fminf(fmaxf(fw, 0.f), (float)(W - 1));
+    return (int)fminf(fmaxf(fw, 0.f), (float)(W - 1));
+}
+
+// The cell of a point.  DEFINITION (exact path): a32 = float32(asin(double t)), atan32 = float32(atan2(double y, double x)),
+// then the reference's float32 / float64 arithmetic.  Round 5: the two fp64 libm calls were the launch (4 M points: ~80 of
+// 120 us); only the CELL depends on them, so a point first brackets both angles with the fp32 functions (OpenCL accuracy:
+// asin <= 4 ulp, atan2 <= 6 ulp; bracket = +-16 ulp) and runs the reference's rounded chain on both ends: every step of
+// it is monotone (rounding is), so equal cells at the two ends ARE the exact path's cell.  The exact path runs only
+// for a point whose bracket straddles a cell boundary (~3e-5 of the points on 32 x 1024 cells), touches the wrap of
+// np.mod at v = 1, or holds a NaN.
+template <bool ELEV64>
+__device__ __forceinline__ void cell_of(float x, float y, float z, int H, int W, double h_up64,
+                                        double h_down64, float& depth, int& gh, int& gw) {
+    depth = sqrtf((x * x + y * y) + z * z);
+    const float t = z / (depth + 1e-6f);
+#ifndef LC_PROJ_EXACT_ONLY
+    {
+        const float af = asinf(t), zf = atan2f(y, x);
+        const float ma = fabsf(af) * 1.9073486e-6f + 1e-30f, mz = fabsf(zf) * 1.9073486e-6f + 1e-30f;   // 16 ulp
+        const int g0 = row_of<ELEV64>(af - ma, H, h_up64, h_down64), g1 = row_of<ELEV64>(af + ma, H, h_up64, h_down64);
+        const float v0 = col_v(zf - mz), v1 = col_v(zf + mz);
+        const int w0 = col_of(v0, W), w1 = col_of(v1, W);
+        const double dlt = h_up64 - h_down64;
+        const bool sane = af == af && zf == zf && dlt == dlt && dlt != 0.0 && fabs(dlt) < 1e30;
+        if (sane && g0 == g1 && w0 == w1 && v0 >= 0.f && v0 < 1.f && v1 >= 0.f && v1 < 1.f) {
+            gh = g0; gw = w0;
+            return;
+        }
+    }
+#endif
+    gh = row_of<ELEV64>((float)asin((double)t), H, h_up64, h_down64);
+    gw = col_of(col_v((float)atan2((double)y, (double)x)), W);
 }
 
 __global__ void zbuf_clear_kernel(unsigned long long* zb, int n) {

@@ -131,7 +131,9 @@ def test_stats_slots_helper():
 
     h = _lib.lib()
     assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 3, 0) == 128 * 4   # 4x64 tiles, 4 px waves
-    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 1, 0) == 0         # 1x1: 2-blocks/CU kernel
+    # 1x1: the 2-blocks/CU kernel, plane folded to 512 x 64, 2 x 64 tiles of 4 pixel waves (it writes entries since round 5)
+    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 1, 0) == 256 * 4
+    assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 3, 5) == 0         # ... its 3x3 launches write none
     assert h.lc_conv2d_ring_f16x2_stats_slots(8, 2, 64, 32, 1024, 3, 0) == 0          # Ci < 24: likewise
     assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 62, 32, 1024, 3, 0) == 0         # Co % 8
 

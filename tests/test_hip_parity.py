@@ -314,6 +314,42 @@ def test_conv_fused_groupnorm_from_pair_stats(dev, B, C, H, W, cfg):
         assert rel_l2(K.conv2d_ring(s1, pk1, wc, None), K.conv2d_ring(s2, pk2, wc, None)) < 2e-6
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(8, 512, 512, 1, 512), (2, 128, 64, 32, 256), (1, 64, 72, 6, 50), (3, 96, 256, 4, 128),
+                                         (2, 256, 512, 1, 100)])
+@pytest.mark.parametrize("cfg", [0, 3, 5, 1, 23])
+def test_conv1x1_statistics_entries(dev, B, Ci, Co, H, W, cfg):
+    """Octet entries from 1x1 launches -- also the non-pipelined kernel's (tiles 1 ... 5: it writes them since round 5;
+    the token projections behind the attention blocks then need no statistics pass): every entry recomputed from the
+    stored output (bias, residual, output scale, ragged planes and channel tails), output identical to the launch
+    without entries, and a GroupNorm fed from them against the statistics-pass route."""
+    from lidarcrafter_amd import ops as K
+
+    x = (seeded_randn(B, Ci, H, W, seed=611) * 1.2 + 0.3).to(dev)
+    w = (seeded_randn(Co, Ci, 1, 1, seed=612) / Ci ** 0.5).to(dev)
+    bias = seeded_randn(Co, seed=613).to(dev)
+    res = seeded_randn(B, Co, H, W, seed=614).to(dev)
+    pk = K.PackedConv()
+    y0 = K.conv2d_ring(x, pk, w, bias, res=res, out_scale=0.7071, tile_cfg=cfg)
+    y = K.conv2d_ring(x, pk, w, bias, res=res, out_scale=0.7071, tile_cfg=cfg, emit_stats=True)
+    assert torch.equal(y, y0)
+    d = getattr(y, "_lc_gnstats", None)
+    if cfg in (3, 5, 1) or (cfg == 0 and (B, Ci, Co, H, W) == (8, 512, 512, 1, 512)):
+        assert d, "the non-pipelined kernel left no entries"
+    if not d:
+        return
+    h = d[(0, Co)]
+    assert h.unit == 8 and tuple(h.buf.shape) == (B, Co // 8, h.slots, 4)
+    e = h.buf.double()
+    n, tot = e[..., 1], e[..., 0] * e[..., 1] + e[..., 2]
+    sq = e[..., 3] + 2 * e[..., 0] * e[..., 2] + e[..., 0] ** 2 * e[..., 1]
+    yo = y.double().view(B, Co // 8, -1)
+    assert bool((n.sum(-1) == 8.0 * H * W).all())
+    assert float((tot.sum(-1) - yo.sum(-1)).abs().max()) < 2e-3 * (H * W) ** 0.5
+    assert float(((sq.sum(-1) - (yo * yo).sum(-1)).abs() / (yo * yo).sum(-1)).max()) < 1e-5
+    G = Co // 8
+    assert rel_l2(K.groupnorm(y, G, 1e-6, act_silu=True), K.groupnorm(y.clone(), G, 1e-6, act_silu=True)) < 2e-6
+
+
 @pytest.mark.parametrize("unit", [8, 2])
 def test_epilogue_statistics_entries_under_load(dev, unit):
     """Every entry the deferred epilogue writes, at the level-0 shape of the bench (8 x 64 x 32 x 1024, fused
@@ -768,6 +804,52 @@ def test_projection_bit_exact(dev, N, H, W, seed):
         assert np.array_equal(cells.cpu().numpy(), np.stack([gh, gw], 1).reshape(-1, 2)), mode
         assert np.array_equal(win.cpu().numpy(), win_r), mode
         assert np.array_equal(img.cpu().numpy(), img_r), mode
+
+
+@pytest.mark.parametrize("H,W", [(32, 1024), (64, 2048), (16, 250)])
+def test_projection_cells_at_boundaries(dev, H, W):
+    """The cell of a point comes from an fp32 bracket of asin / atan2 when both ends of the bracket give one cell, and from
+    the exact path (fp64 asin / atan2 rounded once: the definition) otherwise (geometry.hip cell_of, round 5).  Points
+    constructed ON the row / column boundaries and a few float32 steps either side of them, on the azimuth wrap (y = +-0,
+    x < 0), on the axes, at the poles and at the origin, plus a large uniform cloud: every cell equals the oracle's."""
+    from lidarcrafter_amd import ops as K
+    from oracle import lidar as L
+
+    g = np.random.default_rng(5)
+    up, down = np.deg2rad(10.0), np.deg2rad(-30.0)
+    rows = down + (up - down) * (1.0 - np.arange(0, H + 1) / H)          # elevation of the row boundaries
+    cols = -np.pi * (2.0 * np.arange(0, W + 1) / W - 1.0)                # azimuth of the column boundaries
+    pts = []
+    for _ in range(6):
+        el = np.repeat(rows, 8) + g.uniform(-3e-7, 3e-7, 8 * (H + 1))
+        az = g.uniform(-np.pi, np.pi, el.size)
+        r = np.exp(g.uniform(np.log(0.8), np.log(95.0), el.size))
+        pts.append(np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1))
+        az = np.repeat(cols, 4) + g.uniform(-6e-7, 6e-7, 4 * (W + 1))
+        el = g.uniform(down, up, az.size)
+        r = np.exp(g.uniform(np.log(0.8), np.log(95.0), az.size))
+        pts.append(np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1))
+    special = np.array([[-1, 0.0, 0], [-1, -0.0, 0], [-5, 1e-7, 0.1], [-5, -1e-7, 0.1], [-5, 1e-38, 0], [-5, -1e-38, 0],
+                        [1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [1e-20, 1e-20, 1e-20],
+                        [3, 4, 1e-30], [3, 4, -1e-30], [1e-3, 0, 50], [1e-3, 0, -50], [np.nan, 1, 1], [1, np.inf, 1]])
+    pts.append(special)
+    pts.append(synth_points(1 << 20, 11)[:, :3].astype(np.float64))
+    p3 = np.concatenate(pts).astype(np.float32)
+    # float32 neighbours of every constructed point (x or y one step up / down): lands on both sides of a boundary
+    nb = p3[: 8 * (H + 1) + 4 * (W + 1)].copy()
+    nb[:, 0] = np.nextafter(nb[:, 0], np.float32(np.inf))
+    nb2 = p3[: 8 * (H + 1) + 4 * (W + 1)].copy()
+    nb2[:, 1] = np.nextafter(nb2[:, 1], np.float32(-np.inf))
+    p3 = np.concatenate([p3, nb, nb2])
+    p4 = np.concatenate([p3, np.ones((p3.shape[0], 1), np.float32)], 1)
+    for mode, omode in (("native", "native_cr"), ("f32", "f32")):
+        with np.errstate(all="ignore"):
+            gh, gw, _ = L.project_cells(p4, H, W, 10.0, -30.0, omode)
+        cells = K.project_points(T(p4).to(dev), H, W, 10.0, -30.0, 1.45, 80.0, return_cells=True, dtype_mode=mode)[2]
+        got = cells.cpu().numpy()
+        ok = np.isfinite(p4).all(1)           # (a NaN / inf point never wins a cell; its reported cell is unspecified)
+        bad = np.nonzero(((got[:, 0] != gh) | (got[:, 1] != gw)) & ok)[0]
+        assert bad.size == 0, (mode, bad[:8], got[bad[:8]], gh[bad[:8]], gw[bad[:8]], p4[bad[:8]])
 
 
 @pytest.mark.parametrize("tag,N,H,W,seed", [("a", 4096, 16, 256, 0), ("b", 34720, 32, 1024, 1)])
