@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (c < a.dv) op[c * a.o_cs + t] = oacc[i][r] * inv;
+                if (c < a.dv) lc_st(op + c * a.o_cs + t, oacc[i][r] * inv);
             }
     }
 }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (c < a.dv) op[c * a.o_cs + t] = oacc[i][r] * inv;
+                if (c < a.dv) lc_st(op + c * a.o_cs + t, oacc[i][r] * inv);
             }
     }
 }

@@ -34,6 +34,9 @@ namespace {
 __device__ unsigned long long lc_dbg[32];
 #endif
 
+#ifndef LC_NP_AUX
+#define LC_NP_AUX LC_DEF_AUX     // cache policy of this kernel's output stores (16 = sc1 write-through, as the other epilogues)
+#endif
 template <class C, bool WIDE = false, bool EMIT = false>   // EMIT: octet statistics entries of the output (1x1 launches, round 5)
 __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void conv_f16x2_kernel(ConvArgsH a) {
     constexpr int HALO = C::HALO, NTAP = C::NTAP, BN = C::BN;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256, (C::BN > 64 && C::NTAP == 9) ? 1 : 2) void con
                 v += res_r[i][r];
                 v *= a.out_scale;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y,
-                                                      co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, 0);
+                                                      co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, LC_NP_AUX);
                 if constexpr (EMIT) {      // per channel octet (m; both lane halves) of this wave's pixels, as the pipelined kernels
                     const int m = r >> 2;
                     if (j == 0 && (r & 3) == 0) {

@@ -95,11 +95,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
         };
         const bool vec = (HW & 3) == 0 && (per & 3) == 0 &&
                          ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0;
+        const __amdgpu_buffer_rsrc_t rs_yp = lc_wt_buf(yp);
         if (vec) {
             for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
                 v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
-                *reinterpret_cast<f32x4*>(yp + i) = v;
+                lc_st4(rs_yp, (unsigned)i * 4u, v);
                 am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
         } else {
@@ -244,14 +245,15 @@ __global__ __launch_bounds__(256) void gn_apply_os_kernel(
         };
         const bool vec = (HW & 3) == 0 && (per & 3) == 0 &&
                          ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15) == 0;
+        const __amdgpu_buffer_rsrc_t rs_yp = lc_wt_buf(yp);
         if (vec) {
             for (long long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(xp + i);
                 v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
-                *reinterpret_cast<f32x4*>(yp + i) = v;
+                lc_st4(rs_yp, (unsigned)i * 4u, v);
             }
         } else {
-            for (long long i = lo + threadIdx.x; i < hi; i += 256) yp[i] = f(xp[i]);
+            for (long long i = lo + threadIdx.x; i < hi; i += 256) lc_st(yp + i, f(xp[i]));
         }
     }
 }
@@ -407,6 +409,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
 // OS: 0 = statistics-pass partials; 1 = producer entries, groups of whole channel octets (the block folds ONE group);
 // 2 = producer entries, 2 or 4 channels per group (GroupNorm32 at 64 / 128 channels, round 5): the octet holds 4 / 2
 // groups, wave w of the block folds group w.
+// Store form of the hi / lo planes: 0 = plain (write-back) stores -- shipped; 2 = write-through (sc1) buffer stores.  Round 5
+// measured 2 and four more write-through forms (inline assembly with v_nop / s_nop wait states, four pixels then eight stores
+// back to back, nontemporal): every correct one costs the pass +9 us at 8 x 128 x 16 x 512 and the C2 step 3-5 %
+// (profiles/r05_level0.txt section 8).
+#ifndef LC_GNS_STORE
+#define LC_GNS_STORE 0
+#endif
 template <int OS>
 __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     const float* __restrict__ x, long long x_bs, const double* __restrict__ part, OctStats2 os,
@@ -593,6 +602,9 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
     if (vec) {
         // four consecutive pixels per thread: 8 float4 channel loads, 2 x 4 contiguous 16-byte stores; the first quad is
         // the one issued ahead of the fold (peeled: a select per load inside the loop compiled to 8 branches)
+        const __amdgpu_buffer_rsrc_t rs_yh = lc_wt_buf(yh);
+        const unsigned lo_off = (unsigned)((long long)C8 * HW * 16);          // the lo plane behind the hi plane (< 4 GiB: host check)
+        (void)rs_yh; (void)lo_off;
         auto quad = [&](const f32x4 (&c4)[8], long long p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -601,8 +613,14 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
                 for (int k = 0; k < 8; ++k) v[k] = c4[k][q];
                 half8_t h8, l8;
                 one(v, h8, l8);
+#if LC_GNS_STORE == 2      // write-through (sc1) buffer stores: developer A/B (profiles/r05_level0.txt section 8)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lc_u32x4, h8), rs_yh, (unsigned)(p + q) * 16u, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lc_u32x4, l8), rs_yh,
+                                                       (unsigned)(p + q) * 16u + lo_off, 0, 16);
+#else                      // write-back: shipped
                 yh[p + q] = h8;
                 yl[p + q] = l8;
+#endif
             }
         };
         long long p = lo + threadIdx.x * 4;
@@ -760,6 +778,7 @@ extern "C" int lc_groupnorm_apply_split(const float* x, int64_t x_bs, const doub
     if (!x || !y_split || !partials || !range || B <= 0 || G <= 0 || C % G) return LC_EINVAL;
     if (C % 16) return LC_EUNSUP;
     const long long HW = (long long)H * W;
+    if (2ll * (C / 8) * HW * 16 >= (1ll << 31)) return LC_EUNSUP;       // 32-bit byte offsets into one sample's planes (as the consumer conv)
     const int nch = gn_chunks(B, G, (long long)(C / G) * HW);
     OctStats2 os{nullptr, nullptr, 0, 0, 0, 0, 3, 3};
     hipLaunchKernelGGL(gn_apply_split_kernel<0>, dim3(split_slabs(B, C, HW), C / 8, B), dim3(256), 0,
@@ -783,6 +802,7 @@ extern "C" int lc_groupnorm_apply_os_split(const float* x, int64_t x_bs, const l
     // channels per group -- one group per wave --, whatever the entries' unit)
     if ((cpg % 8 && cpg != 2 && cpg != 4) || os.c0 % 8 || C % 16) return LC_EUNSUP;
     const long long HW = (long long)H * W;
+    if (2ll * (C / 8) * HW * 16 >= (1ll << 31)) return LC_EUNSUP;
     const dim3 grid(split_slabs(B, C, HW), C / 8, B);
     if (cpg % 8 == 0)
         hipLaunchKernelGGL(gn_apply_split_kernel<1>, grid, dim3(256), 0, lc_s(s), x, (long long)x_bs, nullptr, os, gamma,

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void down2_kernel(const float* __restrict__ x,
             }
             acc += k[a] * hz;
         }
-        yb[e] = acc;
+        lc_st(yb + e, acc);
     }
 }
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void down2_vec_kernel(const float* __restrict_
             acc1 += k[a] * hz1;
         }
         float2 o; o.x = acc0; o.y = acc1;
-        *reinterpret_cast<float2*>(yb + ((long long)c * Ho + i) * Wo + w0 / 2) = o;
+        lc_st2(yb + ((long long)c * Ho + i) * Wo + w0 / 2, o);
         if (ostats) {                                          // (uniform)
             const float piv = __builtin_amdgcn_readfirstlane(acc0);
             const float d0 = acc0 - piv, d1 = acc1 - piv;
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ x, l
         top.y = 0.25f * od[0] + 0.75f * od[1];
         bot.x = 0.75f * ev[1] + 0.25f * ev[2];
         bot.y = 0.75f * od[1] + 0.25f * od[2];
-        *reinterpret_cast<float2*>(yc) = top;
-        *reinterpret_cast<float2*>(yc + W2) = bot;
+        lc_st2(yc, top);
+        lc_st2(yc + W2, bot);
     }
 }
 
