@@ -1,6 +1,9 @@
 # round 5: clean A/B of the write-through (sc1) stores in the resampling kernels, the attention output, the fp32 GroupNorm apply
 # kernels and the non-pipelined conv kernel: shipped library against devtools/variants/liblc_wt0.so (all of them write-back);
 # both with the step's verification on
+# (the variant: resample.hip / attention.hip / norm.hip compiled with -DLC_ST_WT=0 and conv_f16x2.hip with -DLC_NP_AUX=0, linked with the
+#  other objects of lidarcrafter_amd/build/ -- devtools/build_var.sh builds one-TU variants the same way; earlier experiments of the
+#  z series reused this file: their outputs are in profiles/r05_second_half_raw.txt)
 export TMPDIR=/tmp
 O=gpurun_out/r05z20
 mkdir -p $O

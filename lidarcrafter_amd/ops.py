@@ -288,14 +288,14 @@ def _attach_stats(out: torch.Tensor, h: _OctStatsHandle) -> None:
 GN_TRACE = None   # developer aid: a collections.Counter of (shape, G, found) per statistics lookup
 
 
-def _find_stats(x: torch.Tensor, G: int, pairs_ok: bool = False, octet_groups: bool = False):
+def _find_stats(x: torch.Tensor, G: int, octet_groups: bool = False):
     """Every consumer folds entries of any unit (8 / 4 / 2 / 1 channels per entry: round 5) as long as a group is a
     whole number of entries.  octet_groups: the consumer is the pre-split apply pass (one block = one channel octet):
-    groups of whole octets, or 2 / 4 channels per group (one group per wave).  (pairs_ok: kept for callers; no effect.)"""
+    groups of whole octets, or 2 / 4 channels per group (one group per wave)."""
     if octet_groups and (x.dim() != 4 or ((x.shape[1] // G) % 8 and x.shape[1] // G not in (2, 4))):
         r = None
     else:
-        r = _find_stats_impl(x, G, True)
+        r = _find_stats_impl(x, G)
     if GN_TRACE is not None:
         why = ""
         if r is None:        # what the tensor does carry (developer trace only)
@@ -306,7 +306,7 @@ def _find_stats(x: torch.Tensor, G: int, pairs_ok: bool = False, octet_groups: b
     return r
 
 
-def _find_stats_impl(x: torch.Tensor, G: int, pairs_ok: bool = False):
+def _find_stats_impl(x: torch.Tensor, G: int):
     """Handles covering all channels of x with at most two segments (each a whole number of
     groups, groups whole entries), or None."""
     if x.dim() != 4:
@@ -1264,7 +1264,7 @@ def groupnorm_stats(x: torch.Tensor, G: int, eps: float, gamma=None, beta=None, 
     for n_, t_ in (("gamma", gamma), ("beta", beta)):
         if t_ is not None:
             _req(t_, n_)
-    hs = _find_stats(x, G, pairs_ok=True) if G <= 128 else None
+    hs = _find_stats(x, G) if G <= 128 else None
     if hs is not None:
         return GnStats((B, C, H, W), None, G, 0, eps, gamma, beta, scale, shift, ss_bs, hs)
     n = lib().lc_groupnorm_partials_elems(B, C, H, W, G)
