@@ -1,5 +1,5 @@
 """Time the pre-split 3x3 conv (GroupNorm-apply output as hi / lo planes -> LDS-DMA kernel) on the C2 layer shapes.
-    LC_HIP_LIB=<variant> python devtools/ps_time.py [B] [--cfg N] [--emit 0|8|4]   (statistics entries: none / octets / quads)"""
+    LC_HIP_LIB=<variant> python devtools/ps_time.py [B] [--cfg N] [--emit 0|8|4] [--shape 0..3]   (statistics entries: none / octets / quads)"""
 import os
 import sys
 import time
@@ -11,10 +11,13 @@ from lidarcrafter_amd import ops as K  # noqa: E402
 
 cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 0
 emit = int(sys.argv[sys.argv.index("--emit") + 1]) if "--emit" in sys.argv else 8
-pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] not in ("--cfg", "--emit")]
+only = int(sys.argv[sys.argv.index("--shape") + 1]) if "--shape" in sys.argv else -1      # one of the four shapes (PMC runs)
+pos = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] not in ("--cfg", "--emit", "--shape")]
 B = int(pos[0]) if pos else 8
 dev = torch.device("cuda:0")
-for (Ci, Co, H, W) in ((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 128), (256, 128, 16, 512)):
+for si, (Ci, Co, H, W) in enumerate(((128, 128, 16, 512), (256, 256, 8, 256), (512, 512, 4, 128), (256, 128, 16, 512))):
+    if only >= 0 and si != only:
+        continue
     x = torch.randn(B, Ci, H, W, device=dev)
     w = torch.randn(Co, Ci, 3, 3, device=dev) / (Ci * 9) ** 0.5
     b = torch.randn(Co, device=dev)
