@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void down2_vec_kernel(const float* __restrict_
     }
 }
 
-// one thread per INPUT pixel -> 2x2 outputs
+// one thread per INPUT pixel -> 2x2 outputs.  (A vector form -- a wave per 256 input columns of a row, float4 loads, neighbours by
+// shuffles, 16-byte stores -- was written and measured in round 5: bit-equal, and TWICE as slow, 29.6 vs ~19 us on the two C2
+// shapes it took, 67.8 vs 29 us on C3's; this kernel writes 4 bytes for every byte it reads and already runs at the rate the
+// write-through path absorbs them.  profiles/r05_level0.txt section 7.)
 __global__ __launch_bounds__(256) void up2_kernel(const float* __restrict__ x, long long x_bs,
                                                  float* __restrict__ y, long long y_bs, int C,
                                                  int H, int W) {

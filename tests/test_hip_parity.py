@@ -540,6 +540,15 @@ def test_resample(dev, B, C, H, W, golden):
     xd = x.to(dev)
     assert rel_l2(K.resample2x(xd, up=False), D.resample_down2(x)) < 1e-6
     assert rel_l2(K.resample2x(xd, up=True), D.resample_up2(x)) < 1e-6
+    if W % 256 == 0:
+        # the vector kernels (aligned rows, W % 256 == 0) against the scalar ones (the same values at a 4-byte-offset address):
+        # same arithmetic order, bit for bit
+        flat = torch.empty(x.numel() + 1, device=dev)
+        xu = flat[1:].view(B, C, H, W)
+        xu.copy_(xd)
+        assert xu.data_ptr() % 16 != 0
+        assert torch.equal(K.resample2x(xd, up=True), K.resample2x(xu, up=True))
+        assert torch.equal(K.resample2x(xd, up=False), K.resample2x(xu, up=False))
     if (B, C, H, W) == (2, 3, 4, 16):
         g = golden("ops")
         assert rel_l2(K.resample2x(xd, up=False), T(g["down_y"])) < 1e-6
