@@ -1013,10 +1013,8 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
         }
     float res_r[C::TCO_][C::TPX_][16];
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
-#ifndef LC_PS_BUFEPI
-#define LC_PS_BUFEPI 1   // 1: residual loads / output stores as raw buffer operations (no branch, no 64-bit address per
-#endif                   //    value: round 5); 0: predicated global loads / stores (developer A/B)
-    // Buffer form: descriptors of sample b (residual: no records when there is none -> zeros); per pixel column j ONE
+    // Residual loads / output stores are raw buffer operations (round 5; before: predicated global loads / stores, a branch and
+    // a 64-bit address per value): descriptors of sample b (residual: no records when there is none -> zeros); per pixel column j ONE
     // byte offset of (channel co_wave, pixel), the value's channel rides in the scalar offset; an out-of-image pixel
     // or a channel past Co is an out-of-range offset.  (Host side: Co * H * W * 4 < 2^31.)
     const unsigned HW4 = (unsigned)HW * 4u;
@@ -1033,7 +1031,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
     auto prefetch_res = [&]() {
 #pragma unroll
         for (int j = 0; j < C::TPX_; ++j) {
-#if LC_PS_BUFEPI
             const unsigned vo = px_off(j);
 #pragma unroll
             for (int i = 0; i < C::TCO_; ++i)
@@ -1043,20 +1040,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                     res_r[i][j][r] = (LC_PS_ABL & 16) ? 0.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                         rs_rb, co_wave + cor < a.Co ? vo : OOB, (unsigned)cor * HW4, 0));
                 }
-#else
-            const int t = wpx * C::TPX_ + j;
-            const int tr = t / C::TPR, tc = t - tr * C::TPR;
-            const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
-            const bool pok = gh < H && gw < W;
-            const long long poff = (long long)gh * W + gw;
-#pragma unroll
-            for (int i = 0; i < C::TCO_; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
-                    res_r[i][j][r] = (rb && pok && co < a.Co && !(LC_PS_ABL & 16)) ? rb[(long long)co * HW + poff] : 0.0f;
-                }
-#endif
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1068,7 +1051,6 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
         __syncthreads();
         half8* t = cur; cur = nxt; nxt = t;
     };
-    float* yb = a.y + (long long)b * a.y_bs;
     for (int tile = 0; tile < tpb; ++tile) {
         for (int ch = ch_lo; ch < last; ++ch) k_iter(ch + 1);
         if (!a.part) prefetch_res();
@@ -1105,9 +1087,7 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
             const int tr = t / C::TPR, tc = t - tr * C::TPR;
             const int gh = h0 + tr, gw = w0 + tc * 32 + l31;
             const bool pok = gh < H && gw < W;
-            const long long poff = (long long)gh * W + gw;
-            const unsigned vo_j = pok ? (unsigned)(co_wave * HW + (int)poff) * 4u : OOB;
-            (void)vo_j; (void)poff;
+            const unsigned vo_j = pok ? (unsigned)(co_wave * HW + gh * W + gw) * 4u : OOB;
             if constexpr (EMIT_STATS) nvalid += __popcll(__ballot(pok) & 0xFFFFFFFFull);
 #pragma unroll
             for (int i = 0; i < C::TCO_; ++i) {
@@ -1116,13 +1096,9 @@ __global__ __launch_bounds__(C::NT, C::NT / 256) void conv_f16x2_ps_kernel(ConvA
                     const int co = co_wave + i * 32 + (r & 3) + 8 * (r >> 2);
                     const float v = ((acc[i][j][r] * out_unscale + bias_r[i][r]) + res_r[i][j][r]) *
                                     a.out_scale;
-#if LC_PS_BUFEPI
                     if (!(LC_PS_ABL & 16))
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_yb, co < a.Co ? vo_j : OOB,
                                                               (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * HW4, LC_DEF_AUX);
-#else
-                    if (pok && co < a.Co && !(LC_PS_ABL & 16)) epi_store(&yb[(long long)co * HW + poff], v);
-#endif
                     if constexpr (EMIT_STATS && !(LC_EMIT_ABL & 1)) {
                         const int m = r >> 2;
                         if (j == 0 && (r & 3) == 0) {
