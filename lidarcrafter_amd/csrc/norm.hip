@@ -754,6 +754,8 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
 }
 
 // ---- pre-split output (see gn_apply_split_kernel) -------------------------------------------------
+// (round 5 sweep of the pixels per block, 256 ... 4096, on the C2 shapes: the choices below are within 1 us of the best
+//  everywhere -- profiles/r05_second_half_raw.txt)
 static int split_slabs(int B, int C, long long HW) {
     int slabs = (int)((HW + 2047) / 2048);                 // >= 2048 pixels (x 8 channels) per block
     if (slabs < 1) slabs = 1;
