@@ -296,6 +296,8 @@ def _find_stats(x: torch.Tensor, G: int, octet_groups: bool = False):
         r = None
     else:
         r = _find_stats_impl(x, G)
+        if octet_groups and r is not None and len(r) == 2 and r[0].channels % 8:
+            r = None         # (the pre-split pass needs the segment boundary on a channel octet: lc_groupnorm_apply_os_split)
     if GN_TRACE is not None:
         why = ""
         if r is None:        # what the tensor does carry (developer trace only)

@@ -163,6 +163,26 @@ def test_producer_stats_bookkeeping():
     assert K._find_stats(buf[:, :, :2], 8) is None             # not a plain channel slice
     K._drop_stats(buf[:, 60:70])                               # overlaps both ranges
     assert K._find_stats(lo, 8) is None and K._find_stats(hi, 8) is None
+    # entry units (round 5): a consumer folds entries of any unit that divides its group; the pre-split apply pass
+    # (octet_groups) additionally wants groups of whole octets or of 2 / 4 channels, and the segment boundary on an octet
+    q0 = K._OctStatsHandle(torch.zeros(1), 64, 3, (B, H * W), 4)    # quad entries
+    p1 = K._OctStatsHandle(torch.zeros(1), 64, 5, (B, H * W), 2)    # pair entries
+    K._attach_stats(lo, q0)
+    K._attach_stats(hi, p1)
+    assert K._find_stats(buf, 32) == (q0, p1)                  # 4 per group: quads and pairs both divide it
+    assert K._find_stats(buf, 32, octet_groups=True) == (q0, p1)
+    assert K._find_stats(buf, 64) is None                      # 2 per group: the quad entries do not
+    assert K._find_stats(hi, 32) == (p1,) and K._find_stats(hi, 32, octet_groups=True) == (p1,)   # 2 per group from pairs
+    assert K._find_stats(buf, 8) == (q0, p1) and K._find_stats(buf, 8, octet_groups=True) == (q0, p1)
+    assert K._find_stats(lo, 16) == (q0,) and K._find_stats(lo, 64) is None          # 4 per group / 1 per group
+    c1 = K._OctStatsHandle(torch.zeros(1), 64, 7, (B, H * W), 1)    # per-channel entries (the x2 down-sampler)
+    K._attach_stats(lo, c1)
+    assert K._find_stats(lo, 64) == (c1,) and K._find_stats(lo, 64, octet_groups=True) is None    # 1 per group: not that pass
+    tri = torch.zeros(B, 96, H, W)                              # 36 + 60 channels: boundary off the octet grid
+    K._attach_stats(tri[:, :36], K._OctStatsHandle(torch.zeros(1), 36, 3, (B, H * W), 2))
+    K._attach_stats(tri[:, 36:], K._OctStatsHandle(torch.zeros(1), 60, 3, (B, H * W), 2))
+    assert K._find_stats(tri, 24) is not None and K._find_stats(tri, 24, octet_groups=True) is None
+    K._drop_stats(buf)
     K._attach_stats(lo, h0)
     K._attach_stats(hi, h1)
     K._drop_stats(hi)
