@@ -136,6 +136,10 @@ def test_stats_slots_helper():
     assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 64, 32, 1024, 3, 5) == 0         # ... its 3x3 launches write none
     assert h.lc_conv2d_ring_f16x2_stats_slots(8, 2, 64, 32, 1024, 3, 0) == 0          # Ci < 24: likewise
     assert h.lc_conv2d_ring_f16x2_stats_slots(8, 64, 62, 32, 1024, 3, 0) == 0         # Co % 8
+    # the x2 down-sampler: one entry per channel, output row and 256-column input segment where its vector kernel runs
+    assert h.lc_resample2x_stats_slots(32, 1024, -1) == 16 * 4
+    assert h.lc_resample2x_stats_slots(32, 1000, -1) == 0 and h.lc_resample2x_stats_slots(31, 1024, -1) == 0
+    assert h.lc_resample2x_stats_slots(32, 1024, 1) == 0                              # up-sampling leaves none
 
 
 def test_producer_stats_bookkeeping():
