@@ -157,33 +157,187 @@ def measure_hbm_traffic(timeout_s: int = 150):
 
 
 def verify_against_reference(ddpm, rank, world, device):
-    """One DDIM step of the BENCH configuration (batch 8, 50-step schedule, x_T from CPU generators
-    seeded with the global sample index -- exactly what the timed loop runs) and the full 50-step
-    run's final frames against the reference's own CPU run (tests/golden/c2_b8.npz, every 4th
-    column).  Rank r checks its own shard when r == 0 (the fixture holds samples 0..7)."""
+    """The full 50-step DDIM run of the BENCH configuration (batch 8, x_T from CPU generators seeded with the
+    GLOBAL sample index -- exactly what the timed loop of this rank runs) against the reference's own CPU run of
+    the same seeds.  EVERY rank checks ITS OWN shard: rank 0 against tests/golden/c2_b8.npz (samples 0..7, states
+    1 / 25 / 50, every 4th column), rank r = 1..7 against tests/golden/c2_shards.npz (samples 8r..8r+7, final
+    state, every 8th column; make_fixtures.py::sec_c2_shards).  Returns this rank's result dict."""
     import numpy as np
 
-    path = os.path.join(ROOT, "tests", "golden", "c2_b8.npz")
-    if rank != 0 or not os.path.exists(path):
-        return None
+    if rank == 0:
+        path, keys = os.path.join(ROOT, "tests", "golden", "c2_b8.npz"), {1: ("x1_s4", 4), 25: ("x25_s4", 4), 50: ("x50_s4", 4)}
+    else:
+        path, keys = os.path.join(ROOT, "tests", "golden", "c2_shards.npz"), {50: (f"shard{rank}_x50_s8", 8)}
+    if rank > 7 or not os.path.exists(path):
+        return {"rank": rank, "ok": None, "why": "no reference fixture for this shard"}
     g = np.load(path)
-    x_T = x_T_for(0, ddpm.sampling_shape, 1).to(device)
+    x_T = x_T_for(rank, ddpm.sampling_shape, world).to(device)
     st = ddpm.begin_sampling(BATCH_PER_GPU, 50, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
     out = {}
     for i in range(1, 51):
         x = ddpm.sampling_step(st)
-        if i in (1, 25, 50):
-            a = x[..., ::4].double().cpu().flatten(1)
-            b = torch.from_numpy(g[f"x{i}_s4"]).double().flatten(1)
+        if i in keys:
+            name, stride = keys[i]
+            a = x[..., ::stride].double().cpu().flatten(1)
+            b = torch.from_numpy(g[name]).double().flatten(1)
             out[f"x{i}"] = float(((a - b).norm(dim=1) / b.norm(dim=1)).max())
     tol = 1e-3
-    ok = all(v < tol for v in out.values())
-    res = {"ok": ok, "tolerance_rel_l2": tol, "max_rel_l2_per_sample": {k: float(f"{v:.3g}") for k, v in out.items()},
-           "against": "tests/golden/c2_b8.npz (the reference's CPU run of C2: batch 8, 50 DDIM steps, "
-                      "same seeds), states 1 / 25 / 50"}
-    if not ok:
+    return {"rank": rank, "samples": [BATCH_PER_GPU * rank, BATCH_PER_GPU * rank + BATCH_PER_GPU - 1],
+            "ok": all(v < tol for v in out.values()),
+            "max_rel_l2_per_sample": {k: float(f"{v:.3g}") for k, v in out.items()},
+            "against": os.path.relpath(path, ROOT)}
+
+
+def verify_all_ranks(ddpm, rank, world, device, dist_on):
+    """Every rank verifies its shard; rank 0 collects the per-rank results (one all_gather_object) and the run
+    stops on every rank if any shard is off."""
+    mine = verify_against_reference(ddpm, rank, world, device)
+    results = [mine]
+    if dist_on and world > 1:
+        import torch.distributed as dist
+
+        results = [None] * world
+        dist.all_gather_object(results, mine)
+    bad = [r for r in results if r["ok"] is False]
+    res = {"ok": not bad and all(r["ok"] for r in results if r["ok"] is not None),
+           "tolerance_rel_l2": 1e-3,
+           "max_rel_l2_per_sample": results[0].get("max_rel_l2_per_sample"),
+           "ranks_verified": sum(1 for r in results if r["ok"]), "per_rank": results,
+           "against": "the reference's CPU run of C2 (batch 8, 50 DDIM steps, same seeds): tests/golden/c2_b8.npz "
+                      "(rank 0: states 1 / 25 / 50), tests/golden/c2_shards.npz (ranks 1..7: final state of "
+                      "global samples 8r..8r+7)"}
+    if bad:
         raise SystemExit(f"bench.py: the bench configuration does not reproduce the reference: {res}")
     return res
+
+
+def box_calibration(device, seconds: float = 0.2):
+    """What THIS box sustains (the pool's boxes spread 229-281 steps/s for one tree): a bare
+    v_mfma_f32_32x32x16_f16 loop on random fp16 operands (the matrix pipes run into the chip's power budget, and
+    the sustained rate depends on the operand bits) and a streaming copy larger than the 256 MB Infinity Cache,
+    ~`seconds` of GPU time each.  Not part of the timed region."""
+    from lidarcrafter_amd import _lib
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream(device).cuda_stream
+    blocks = 512
+    ops = (torch.rand(blocks * 512 * 4 * 8, device=device) * 2 - 1).to(torch.float16)
+    sink = torch.empty(blocks * 512, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def mfma(iters):
+        e0.record()
+        fl = L.lc_calibrate_mfma_f16(ops.data_ptr(), blocks, iters, sink.data_ptr(), st)
+        e1.record()
+        e1.synchronize()
+        assert fl > 0, fl
+        return fl, e0.elapsed_time(e1) * 1e-3
+
+    mfma(200)
+    fl, t = mfma(2000)
+    iters = max(2000, int(2000 * seconds / max(t, 1e-6) / 4))
+    rates = []
+    for _ in range(4):
+        fl, t = mfma(iters)
+        rates.append(fl / t / 1e12)
+    n = 1 << 28                                             # 1 GiB of floats each way
+    src = torch.empty(n, device=device).normal_()
+    dst = torch.empty(n, device=device)
+    reps = 0
+    for k in range(2):
+        e0.record()
+        reps = 3 if k == 0 else max(3, int(seconds / max(tc, 1e-6)))
+        for _ in range(reps):
+            rc = L.lc_calibrate_stream_copy(src.data_ptr(), dst.data_ptr(), n, st)
+            assert rc == 0, rc
+        e1.record()
+        e1.synchronize()
+        tc = e0.elapsed_time(e1) * 1e-3 / reps
+    del src, dst
+    mf = sorted(rates)[len(rates) // 2]
+    return {"mfma_f16_tflops_random_operands": round(mf, 1),
+            "three_product_ceiling_tflops": round(mf / 3, 1),
+            "stream_copy_tb_s": round(2 * 4 * n / tc / 1e12, 3),
+            "how": f"lc_calibrate_mfma_f16: {blocks} blocks x 8 waves, 4 accumulators, {iters} x 16 MFMAs per wave, "
+                   f"median of 4 launches; lc_calibrate_stream_copy: 1 GiB -> 1 GiB float4 copy, read + write bytes, "
+                   f"{reps} launches"}
+
+
+def extra_rows(device, steps_small: int = 20):
+    """Same-process rows next to the headline: the C2 shape at batch 1 and batch 32 and the
+    C3 shard (layout-conditioned denoiser, batch 8) -- ms per denoising step through the graph-replayed sampler,
+    each behind its own check against the reference's outputs (tests/golden/c2_b8.npz, c3_b8.npz)."""
+    import numpy as np
+
+    from lidarcrafter_amd.testing import seeded_fill, seeded_randn, synth_layout_batch
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as CONFIGS
+
+    def rel(a, b):
+        a, b = a.double().cpu().flatten(1), b.double().flatten(1)
+        return float(((a - b).norm(dim=1) / b.norm(dim=1)).max())
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    rows = {}
+    g = np.load(os.path.join(ROOT, "tests", "golden", "c2_b8.npz"))
+    ddpm, _ = build_ddpm(device)
+    x8 = seeded_randn(8, 2, 32, 1024, seed=81).to(device)
+    lam8 = torch.from_numpy(g["lam"]).to(device)
+    want = torch.from_numpy(g["y_s4"])
+    for B, n in ((1, steps_small), (32, max(5, steps_small // 2))):
+        with torch.no_grad():
+            if B == 1:
+                r = max(rel(ddpm.model(x8[k:k + 1].contiguous(), lam8[k:k + 1])[..., ::4], want[k:k + 1]) for k in (0, 5))
+            else:
+                r = rel(ddpm.model(x8.repeat(4, 1, 1, 1), lam8.repeat(4))[..., ::4], want.repeat(4, 1, 1, 1))
+        if not r < 2e-5:
+            raise SystemExit(f"bench.py rows: batch-{B} forward is {r} from the reference's output")
+        gen = [torch.Generator().manual_seed(i) for i in range(B)]
+        x_T = torch.stack([torch.randn(*ddpm.sampling_shape, generator=q) for q in gen]).to(device)
+        st = ddpm.begin_sampling(B, n + 6, rng=None, mode="ddim", ddim_eta=0.0, x_T=x_T)
+        dt = timed(lambda: ddpm.sampling_step(st), n)
+        assert torch.isfinite(st["x"]).all()
+        rows[f"uncond_32x1024_batch{B}"] = {
+            "ms_per_step": round(dt * 1e3, 3), "sample_steps_per_s": round(B / dt, 1),
+            "algorithmic_tflops": round(B * GFLOP_PER_SAMPLE_STEP / dt / 1e3, 1),
+            "check": {"forward_max_rel_l2_vs_reference": float(f"{r:.3g}"), "tolerance": 2e-5,
+                      "against": "tests/golden/c2_b8.npz y_s4 (samples of a batch are independent in the reference)"}}
+    del ddpm
+    g = np.load(os.path.join(ROOT, "tests", "golden", "c3_b8.npz"))
+    cfg = CONFIGS["nuscenes-box-layout-v6"]()
+    ddpm, model, _ = inference.load_model_duffusion_training(cfg)
+    seeded_fill(model, salt=200), seeded_fill(ddpm.condition_model, salt=201)
+    ddpm = ddpm.eval().to(device)
+    batch = {k: v.to(device) for k, v in synth_layout_batch(8, 32, 1024, seed=83).items()}
+    x = seeded_randn(8, 2, 32, 1024, seed=84).to(device)
+    with torch.inference_mode():
+        cond = ddpm.condition_model(batch)
+        y = ddpm.model(x, {"time_condition": torch.from_numpy(g["lam"]).to(device), "other_condition": cond})
+        r = rel(y[..., ::4], torch.from_numpy(g["y_s4"]))
+        if not r < 2e-5:
+            raise SystemExit(f"bench.py rows: C3 forward is {r} from the reference's output")
+        gen = [torch.Generator().manual_seed(40 + i) for i in range(8)]
+        x_T = ddpm.randn(8, *ddpm.sampling_shape, rng=gen, device=ddpm.device)
+        cdict = ddpm.get_network_condition(input_dict=batch, only_custom_condition=True)
+        n = max(5, steps_small // 2)
+        st = ddpm.begin_sampling(8, n + 6, None, "ddim", 0.0, x_T=x_T, condition_dict=cdict)
+        dt = timed(lambda: ddpm.sampling_step(st), n)
+        assert torch.isfinite(st["x"]).all()
+    rows["cond_layout_v6_32x1024_batch8"] = {
+        "ms_per_step": round(dt * 1e3, 3), "sample_steps_per_s": round(8 / dt, 1),
+        "algorithmic_tflops": round(8 * 255.9 / dt / 1e3, 1),
+        "check": {"forward_max_rel_l2_vs_reference": float(f"{r:.3g}"), "tolerance": 2e-5,
+                  "against": "tests/golden/c3_b8.npz y_s4 (C3 shard: nuscenes-box-layout-v6, batch 8)"}}
+    return rows
 
 
 def main():
@@ -198,6 +352,8 @@ def main():
                     help="skip the golden-vector check of the bench configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-rows", action="store_true",
+                    help="skip the same-process secondary rows (batch 1 / 32, C3) and the box calibration")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU,
@@ -256,7 +412,7 @@ def main():
     # reported as config.graph_setup_steps) -- the W warmup and K timed steps are all graph replays.
     verify = None
     if not args.no_verify and BATCH_PER_GPU == 8:
-        verify = verify_against_reference(ddpm, rank, world, device)
+        verify = verify_all_ranks(ddpm, rank, world, device, dist_on)
     setup = max(0, 2 - args.warmup)
     total = setup + args.warmup + args.steps * args.repeat
     x_T = x_T_for(rank, ddpm.sampling_shape, world).to(device)
@@ -374,6 +530,16 @@ def main():
         ctypes.CDLL(None).fflush(None)
         dist.barrier()
 
+    calib = rows = None
+    if rank == 0 and world == 1 and not args.no_rows:
+        calib = box_calibration(device)
+        if BATCH_PER_GPU == 8:
+            rows = extra_rows(device)
+        if roof is not None and K.CONV_PRECISION == "f16x2":
+            roof["frac_of_box_ceiling"] = round(roof["achieved"] / calib["three_product_ceiling_tflops"], 4)
+            roof["box_ceiling_note"] = ("achieved / (this box's bare-MFMA rate on random operands / 3 products): the "
+                                        "fraction of what the matrix pipes of THIS box sustain that the 3x3 family "
+                                        "delivers; `frac` stays against the 2.5 PFLOP/s data-sheet peak")
     if rank == 0:
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # N = 1 only (contract)
         steps_per_s = world * args.steps / dt
@@ -413,6 +579,7 @@ def main():
                        "algorithmic_tflops": round(
                            steps_per_s * BATCH_PER_GPU * GFLOP_PER_SAMPLE_STEP / 1e3, 2)},
             "roofline": roof, "cpu_baseline": cpu,
+            "box_calibration": calib, "rows": rows,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

@@ -32,8 +32,10 @@ extern "C" {
 
 typedef void* lc_stream_t;
 
-/* Library / device probe.  Returns the ABI version (this header = 2: round 3 -- field-of-view
- * arguments are doubles, lc_layout_condition takes float32 or float64 boxes, float64 point sets). */
+/* Library / device probe.  Returns the ABI version (this header = 3: round 6 -- lc_conv2d_ring_f16x2_ps_fwd carries
+ * gn_ostats_unit, the stride-2 / calibration entry points exist; 2: round 3 -- field-of-view arguments are doubles,
+ * lc_layout_condition takes float32 or float64 boxes, float64 point sets).  Bumped whenever an exported signature
+ * changes; lidarcrafter_amd/_lib.py refuses a library of another version. */
 int lc_abi_version(void);
 /* Writes gcnArchName of the current device into buf (NUL terminated). */
 int lc_device_arch(char* buf, int buflen);
@@ -397,6 +399,15 @@ int lc_pstep_fwd(const float* x_t, int64_t xt_bs, const float* pred, int64_t pre
 int lc_gate_bias_act(const float* x, int64_t x_bs, const float* gate_logit, const float* bias,
                      int64_t gb_bs, const float* res, int64_t res_bs, float* y, int64_t y_bs,
                      int B, int C, int N, int act, lc_stream_t s);
+
+/* Box calibration for bench.py (`box_calibration`): what THIS box's matrix pipes and memory sustain, so that numbers of
+ * different boxes of the pool can be compared.  No counterpart in the reference.
+ * lc_calibrate_mfma_f16: `blocks` blocks of 8 waves run `iters` x 16 v_mfma_f32_32x32x16_f16 per wave on the caller's
+ * operands (blocks * 512 * 4 half8 vectors = blocks * 32 KiB of fp16; random data: the sustained rate depends on the
+ * operand bits), one float per thread into sink[blocks * 512].  Returns the FLOPs of the launch (> 0) or a negative code.
+ * lc_calibrate_stream_copy: dst[i] = src[i], n floats (multiple of 4, 16-byte aligned), float4 grid-stride. */
+int64_t lc_calibrate_mfma_f16(const void* operands, int blocks, int iters, float* sink, lc_stream_t s);
+int lc_calibrate_stream_copy(const float* src, float* dst, int64_t n, lc_stream_t s);
 
 /* Strided copy of [B, C*H*W] blocks (fills a channel slice of a concat buffer). */
 int lc_copy_strided(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int64_t n,

@@ -102,6 +102,8 @@ SIGNATURES = {
     "lc_attention_bwd_f16x2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "lc_gate_bias_act": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "lc_calibrate_mfma_f16": (i64, [vp, i32, i32, vp, vp]),
+    "lc_calibrate_stream_copy": (i32, [vp, vp, i64, vp]),
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),
     "lc_add_scale": (i32, [vp, i64, vp, i64, vp, i64, i32, i64, f32, vp]),
     "lc_project_points": (i32, [vp, i32, i32, i32, f64, f64, f32, f32, vp, vp, vp, vp, i32, vp]),
@@ -134,6 +136,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 3   # include/lidarcrafter_hip.h lc_abi_version: bumped with every change of an exported signature
 
 
 class HipLibraryMissing(RuntimeError):
@@ -152,7 +155,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.lc_abi_version() != 2:
+        if handle.lc_abi_version() != ABI_VERSION:
             raise HipLibraryMissing("ABI version mismatch, rebuild the library")
         _lib = handle
     return _lib

@@ -12,7 +12,7 @@
 //            48 KB (x: 2 planes x 4 x 256 units, w: 2 planes x 4 x 128 units), 48 DMA wave-instructions per chunk
 //
 // Same arithmetic as every f16x2 kernel: wh*xh + wh*xl + wl*xh in fp32, * 1 / (x_scale * w_scale), + bias (+ res),
-// * out_scale.  Needs Ci % 32 == 0.  First measurement (devtools/variants/ps1x1/README.md): GroupNorm + projection
+// * out_scale.  Needs Ci % 32 == 0.  First measurement (the candidate's harness of round 5): GroupNorm + projection
 // 256 -> 768 @ 8 x 256, batch 8: 74.9 -> 54.4 us; 512 -> 1536 @ 4 x 128: 64.8 -> 39.9 us.
 #pragma once
 

@@ -447,7 +447,11 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_tall_kernel(ConvArgsH a) {
             __builtin_amdgcn_sched_barrier(0);
             if (!(LC_TALL_ABL & 8) && C * NTAP + tap < DE::NUSED) de.slot(C * NTAP + tap);
             // this tap's weight DMA piece BEHIND the deferred slot: the wait in front of the chunk barrier then leaves
-            // exactly the later taps' deferred operations in flight (a reordering by hipcc only makes it stricter)
+            // exactly the later taps' deferred operations in flight.  The count is by hand (the DMA is inline assembly,
+            // invisible to hipcc's vmcnt tracking): it holds as long as every counted operation really is issued behind
+            // the last piece -- an operation hipcc hoists in front of it, merges or drops would let a piece stay in
+            // flight across the barrier.  tests/test_isa_audit.py::test_tall_kernel_chunk_barrier_waits_cover_the_weight_dma
+            // checks exactly that on the disassembly of every instantiation.
             if (tap < KW && !(LC_TALL_ABL & 16)) dma_w(wnext, tap, NC);
             if (AH == 2 && tap == KW) load_x(xl, LC);
             if (tap == LC_TALL_T0) stage_px(xst, 0, dreg_b);

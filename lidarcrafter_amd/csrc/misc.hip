@@ -154,6 +154,39 @@ __global__ __launch_bounds__(256) void add_scale_kernel(const float* __restrict_
         yp[i] = (ap[i] + bp[i]) * scale;
 }
 
+// ---- box calibration (bench.py: `box_calibration`) ---------------------------------------------------------------
+// A bare v_mfma_f32_32x32x16_f16 loop on operands the CALLER supplies (random fp16: the chip clocks to its power budget,
+// and what a matrix pipe sustains depends on the operand bits -- profiles/r01_e_ubench_mfma.txt: 2.24 PFLOP/s on zeros,
+// 1.69 on random data), 4 independent accumulators per wave, 8 waves per block; and a streaming float4 copy.
+typedef _Float16 cal_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void calib_mfma_kernel(const cal_half8* __restrict__ ops, int iters, float* __restrict__ sink) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int t = blockIdx.x * 512 + threadIdx.x;
+    cal_half8 a[2], b[2];
+    a[0] = ops[4 * t]; a[1] = ops[4 * t + 1]; b[0] = ops[4 * t + 2]; b[1] = ops[4 * t + 3];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 1], b[(i >> 1) ^ (rep & 1)], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    sink[t] = s;
+}
+__global__ __launch_bounds__(256) void calib_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 inline int grid_for(long long n) {
     long long g = (n + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -161,7 +194,23 @@ inline int grid_for(long long n) {
 
 }  // namespace
 
-extern "C" int lc_abi_version(void) { return 2; }
+extern "C" int lc_abi_version(void) { return 3; }
+
+extern "C" int64_t lc_calibrate_mfma_f16(const void* operands, int blocks, int iters, float* sink, lc_stream_t s) {
+    if (!operands || !sink || blocks <= 0 || iters <= 0) return LC_EINVAL;
+    hipLaunchKernelGGL(calib_mfma_kernel, dim3(blocks), dim3(512), 0, lc_s(s), reinterpret_cast<const cal_half8*>(operands),
+                       iters, sink);
+    const int rc = lc_launch_status();
+    if (rc != LC_OK) return rc < 0 ? rc : -rc;
+    return 2ll * 32 * 32 * 16 * 16 * (int64_t)iters * 8 * blocks;     // flops of the launch
+}
+
+extern "C" int lc_calibrate_stream_copy(const float* src, float* dst, int64_t n, lc_stream_t s) {
+    if (!src || !dst || n <= 0 || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return LC_EINVAL;
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, lc_s(s), reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), (long long)(n / 4));
+    return lc_launch_status();
+}
 
 // Loads every translation unit's code object for the current device (HIP defers that to the unit's first launch; a
 // first sampling step otherwise pays ~15 loads).  Idempotent; lidarcrafter_amd.ops.prepare_model calls it.

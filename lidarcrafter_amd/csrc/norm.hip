@@ -439,10 +439,15 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(
         // unconditional loads (a predicated load is an exec-mask branch, and hipcc's waits across branches are vmcnt(0)):
         // a thread without a first quad re-reads the slab's last quad and never uses it (C % 16 == 0: 16 channels x HW
         // floats behind x always hold 16 bytes)
+        // Only the vector path consumes them.  Off it (HW % 4 != 0 or a slab / pointer that is not 16-byte aligned) a typed
+        // 16-byte load from xp would be misaligned: every thread then reads the 16-byte aligned word at or below x instead
+        // (inside x's allocation: allocation bases are 16-byte aligned) -- still no branch, and nothing is read for nothing
+        // beyond that one cached line.
         long long p0 = lo + threadIdx.x * 4;
         p0 = p0 < hi - 4 ? p0 : hi - 4;
-        const float* src = HW >= 4 ? xp + (p0 > 0 ? p0 : 0) : x;
-        const long long cs = HW >= 4 ? HW : 0;
+        const float* x_al = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(x) & ~static_cast<uintptr_t>(15));
+        const float* src = vec ? xp + (p0 > 0 ? p0 : 0) : x_al;
+        const long long cs = vec ? HW : 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c4_first[k] = *reinterpret_cast<const f32x4*>(src + (long long)k * cs);
         asm volatile("" ::: "memory");

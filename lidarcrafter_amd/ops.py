@@ -626,7 +626,8 @@ def can_presplit(C: int, G: int) -> bool:
 
 # 1x1 projections with many output channels take a pre-split input too (lc_conv1x1_f16x2_ps_fwd): the fp32-input 1x1
 # kernel splits the same input tile once per 64-channel output block.  Measured ahead from 512 output channels
-# (devtools/variants/ps1x1/README.md); LC_PS1X1_MIN_CO=0 turns the route off.
+# (GroupNorm + projection 256 -> 768 @ 8 x 256 at batch 8: 74.9 -> 54.4 us; 512 -> 1536 @ 4 x 128: 64.8 -> 39.9 us -- the
+# candidate's own harness, round 5, recorded in DESIGN.md section 9.4); LC_PS1X1_MIN_CO=0 turns the route off.
 PS1X1_MIN_CO = int(_os.environ.get("LC_PS1X1_MIN_CO", "512"))
 
 
@@ -937,8 +938,9 @@ def conv2d_ring(x: torch.Tensor, packed: PackedConv, weight: torch.Tensor,
 
     emit_stats: True / 8 = the conv also leaves per-octet GroupNorm statistics of what it stores (2 =
     per channel pair, for a consumer GroupNorm with 2 / 4 / 6 channels per group; 4 = per channel quad, for
-    4 / 12 per group: the pre-split kernel writes quads, the fp32-input kernels the finer pairs), attached to
-    the output tensor object; a following `groupnorm` / `groupnorm_stats` of that tensor (or of a
+    4 / 12 per group: the pre-split kernel writes quads, the fp32-input kernels the finer pairs; a 1x1 launch of
+    the fp32-input kernels writes octet entries only -- asked for pairs / quads it leaves NO statistics and the
+    consumer runs its own statistics pass), attached to the output tensor object; a following `groupnorm` / `groupnorm_stats` of that tensor (or of a
     concat buffer whose halves both carry them) then skips its statistics pass.  Every wrapper of
     this module that writes into an `out=` tensor forgets the statistics of what it overwrites;
     a caller who modifies such a tensor with a torch in-place op must not request them (inference
@@ -1544,13 +1546,19 @@ def project_points(points: torch.Tensor, H: int, W: int, fov_up: float, fov_down
     return (img, win, cells) if return_cells else (img, win)
 
 
+PIB_MAX_BOXES = 1250   # csrc/geometry.hip: 12 floats per box in LDS (60 000 bytes); larger sets run in slabs
+
+
 def points_in_boxes_mask(points: torch.Tensor, boxes: torch.Tensor, margin: float) -> torch.Tensor:
     _req(points, "points"), _req(boxes, "boxes")
     points, boxes = points.contiguous(), boxes.contiguous()
-    out = torch.empty((boxes.shape[0], points.shape[0]), device=points.device, dtype=torch.int32)
-    check(lib().lc_points_in_boxes_mask(boxes.data_ptr(), boxes.shape[0], points.data_ptr(),
-                                        points.shape[0], float(margin), out.data_ptr(), _stream()),
-          "lc_points_in_boxes_mask")
+    K = boxes.shape[0]
+    out = torch.empty((K, points.shape[0]), device=points.device, dtype=torch.int32)
+    for k0 in range(0, K, PIB_MAX_BOXES):                  # rows of `out` are per box: slabs are independent
+        k1 = min(K, k0 + PIB_MAX_BOXES)
+        check(lib().lc_points_in_boxes_mask(boxes[k0:k1].data_ptr(), k1 - k0, points.data_ptr(),
+                                            points.shape[0], float(margin), out[k0:k1].data_ptr(), _stream()),
+              "lc_points_in_boxes_mask")
     return out
 
 
@@ -1558,10 +1566,21 @@ def points_in_boxes_index(points: torch.Tensor, boxes: torch.Tensor, margin: flo
     _req(points, "points"), _req(boxes, "boxes")
     points, boxes = points.contiguous(), boxes.contiguous()
     B, M, _ = points.shape
+    K = boxes.shape[1]
     out = torch.empty((B, M), device=points.device, dtype=torch.int32)
-    check(lib().lc_points_in_boxes_index(boxes.data_ptr(), points.data_ptr(), B, boxes.shape[1], M,
-                                         float(margin), out.data_ptr(), _stream()),
-          "lc_points_in_boxes_index")
+    if K <= PIB_MAX_BOXES:
+        check(lib().lc_points_in_boxes_index(boxes.data_ptr(), points.data_ptr(), B, K, M,
+                                             float(margin), out.data_ptr(), _stream()),
+              "lc_points_in_boxes_index")
+        return out
+    out.fill_(-1)                                          # first containing box wins (roiaware_pool3d_kernel.cu:313-336)
+    part = torch.empty_like(out)
+    for k0 in range(0, K, PIB_MAX_BOXES):
+        slab = boxes[:, k0:k0 + PIB_MAX_BOXES].contiguous()
+        check(lib().lc_points_in_boxes_index(slab.data_ptr(), points.data_ptr(), B, slab.shape[1], M,
+                                             float(margin), part.data_ptr(), _stream()),
+              "lc_points_in_boxes_index")
+        torch.where((out < 0) & (part >= 0), part + k0, out, out=out)
     return out
 
 
@@ -1641,9 +1660,21 @@ def points_in_boxes_mask4(points: torch.Tensor, boxes: torch.Tensor, margin: flo
     K = boxes.shape[0]
     mask = torch.empty((K, N), device=points.device, dtype=torch.int32) if want_mask else None
     cnt = torch.empty((N,), device=points.device, dtype=torch.int32) if want_count else None
-    if N > 0 and K > 0:
+    if N > 0 and 0 < K <= PIB_MAX_BOXES:
         check(lib().lc_points_in_boxes_mask4(boxes.data_ptr(), K, points.data_ptr(), N, float(margin),
                                              _p(mask), _p(cnt), _stream()), "lc_points_in_boxes_mask4")
+    elif N > 0 and K > 0:                                  # slabs of boxes: mask rows are per box, the counts add up
+        if cnt is not None:
+            cnt.zero_()
+            part = torch.empty_like(cnt)
+        for k0 in range(0, K, PIB_MAX_BOXES):
+            k1 = min(K, k0 + PIB_MAX_BOXES)
+            check(lib().lc_points_in_boxes_mask4(boxes[k0:k1].data_ptr(), k1 - k0, points.data_ptr(), N, float(margin),
+                                                 _p(mask[k0:k1]) if mask is not None else None,
+                                                 _p(part) if cnt is not None else None, _stream()),
+                  "lc_points_in_boxes_mask4")
+            if cnt is not None:
+                cnt += part
     elif cnt is not None:
         cnt.zero_()
     return mask, cnt

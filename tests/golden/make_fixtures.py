@@ -22,7 +22,7 @@ import _ref_import as R  # noqa: E402
 R.install()
 from lidarcrafter_amd.testing import seeded_fill, seeded_randn, synth_points  # noqa: E402
 
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("LC_FIXTURE_THREADS", "8")))
 torch.manual_seed(0)
 
 
@@ -329,6 +329,25 @@ def sec_c2():
         out[f"x{i}_s4"] = _strided(xs[i])
         out[f"x{i}_norm"] = xs[i].flatten(1).norm(dim=1)
     save("c2_b8", **out)
+
+
+def sec_c2_shards():
+    """The C2 run of `sec_c2` for the shards a multi-GPU bench owns beyond rank 0: global samples
+    8 ... 63 (rank r of `bench.py --gpus N` draws x_T from generators seeded 8 r + i,
+    lidarcrafter_amd.parallel.shard_generators).  Per shard: the final state of the reference's
+    50-step DDIM run, every 8th column of every sample and row, plus the full-frame norms."""
+    eu = R.ref("models.unets.efficient_unet")
+    df = R.ref("models.diffusion")
+    m = _build_uncond(eu, 64, (32, 1024))
+    ddpm = df.ContinuousTimeGaussianDiffusion(m, torch.nn.Identity()).eval()
+    out = {}
+    for r in range(1, 8):
+        rng = [torch.Generator().manual_seed(8 * r + i) for i in range(8)]
+        x = ddpm.sample(8, 50, progress=False, rng=rng, mode="ddim")
+        out[f"shard{r}_x50_s8"] = _strided(x, 8)
+        out[f"shard{r}_x50_norm"] = x.flatten(1).norm(dim=1)
+        print(f"  shard {r} done", flush=True)
+    save("c2_shards", **out)
 
 
 def sec_c3():

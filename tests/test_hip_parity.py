@@ -1019,6 +1019,26 @@ def test_points_in_boxes_bit_exact(dev, golden):
     assert np.array_equal(idx.cpu().numpy(), OB.points_in_boxes_index(pts2, bx2, 1e-5))
 
 
+def test_points_in_boxes_more_boxes_than_one_launch(dev):
+    """a launch holds 1250 boxes in LDS; the ops chunk larger sets (mask rows per slab, counts added, first
+    containing box across slabs) -- bit-exact against the C restatement at 2600 boxes."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_boxes
+    from oracle import boxes as OB
+
+    pts = synth_points(4096, 15)[:, :3].copy()
+    bx = np.concatenate([synth_boxes(13, pts, 20 + i) for i in range(200)])
+    assert bx.shape[0] == 2600 > K.PIB_MAX_BOXES
+    ref = OB.points_in_boxes_mask(pts, bx, 1e-2)
+    p4 = np.concatenate([pts, np.zeros((4096, 1), np.float32)], 1)
+    m4, cnt = K.points_in_boxes_mask4(T(p4).to(dev), T(bx).to(dev), 1e-2)
+    assert np.array_equal(m4.cpu().numpy(), ref) and np.array_equal(cnt.cpu().numpy(), ref.sum(0))
+    m = K.points_in_boxes_mask(T(pts).to(dev), T(bx).to(dev), 1e-2)
+    assert np.array_equal(m.cpu().numpy(), ref)
+    idx = K.points_in_boxes_index(T(pts[None]).to(dev), T(bx[None]).to(dev), 1e-5)
+    assert np.array_equal(idx.cpu().numpy(), OB.points_in_boxes_index(pts[None], bx[None], 1e-5))
+
+
 def test_load_points_as_images_api(dev, golden):
     from lidargen.dataset.transforms_3d.common import load_points_as_images
     from oracle import lidar as L

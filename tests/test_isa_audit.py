@@ -4,7 +4,10 @@ found in epilogues the hard way (profiles/r05_level0.txt sections 7-8):
     between; hipcc inserts them for stores it knows, NOT behind inline assembly): corrupted planes / statistics entries;
   * system-scope (`sc0 sc1`) stores -- what `volatile` stores compile to, each followed by `s_waitcnt vmcnt(0)`: +6 ... +11 us
     per launch of the pre-split convolution;
-  * an IEEE division (`v_div_scale_f32`) in the GroupNorm apply passes' SiLU."""
+  * an IEEE division (`v_div_scale_f32`) in the GroupNorm apply passes' SiLU;
+and the hand-counted `s_waitcnt vmcnt(N)` in front of the tall convolution kernel's chunk barriers: the weight
+LDS-DMA is inline assembly that hipcc cannot count, so the ISA itself must show at least N VMEM operations between a chunk's
+last DMA piece and the wait."""
 import glob
 import os
 import re
@@ -71,3 +74,47 @@ def test_no_ieee_division_in_the_groupnorm_apply_passes(kernels):
     for k in ks:
         n = sum(1 for i in kernels[k] if i.startswith("v_div_scale_f32"))
         assert n == 0, (k[:70], n)
+
+
+_VMEM = re.compile(r"^(buffer|global|flat|scratch)_(load|store|atomic)")
+
+
+def test_tall_kernel_chunk_barrier_waits_cover_the_weight_dma(kernels):
+    """conv_f16x2_tall.hip k_iter: `wait_vmcnt(later)` + bare `s_barrier` per chunk, `later` = the deferred-epilogue
+    operations (+ x loads) issued BEHIND the chunk's last weight-DMA piece.  VMEM operations return in order, so the
+    pieces have landed at the barrier iff at least `later` VMEM instructions really follow the last
+    `buffer_load_dwordx4 ... lds` -- if hipcc hoists, merges or drops one of the counted operations the wait lets a piece
+    stay in flight across the barrier (a silent LDS race).  Checked on the disassembly of every instantiation: for each
+    barrier with a vmcnt(N > 0) wait in front of it, the VMEM instructions between the last LDS-DMA and the wait number
+    >= N (the strictest wait in front of the barrier counts: hipcc may add its own)."""
+    ks = {k: v for k, v in kernels.items() if "conv_f16x2_tall_kernel" in k and not k.startswith("__")}
+    assert len(ks) >= 12, sorted(ks)[:3]
+    for name, ins in ks.items():
+        nch = int(re.search(r"tall_kernelILi(\d+)E", name).group(1))
+        steady = 0
+        for b, t in enumerate(ins):
+            if not t.startswith("s_barrier"):
+                continue
+            waits, j = [], b - 1
+            while j > 0 and b - j <= 12:                 # the waits directly in front of the barrier
+                m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", ins[j])
+                if m:
+                    waits.append((int(m.group(1)), j))
+                elif _VMEM.match(ins[j]) or ins[j].startswith("v_mfma"):
+                    break
+                j -= 1
+            if not waits:
+                continue                                  # a prologue __syncthreads (GroupNorm fold): no DMA accounting
+            n, at = min(waits)
+            if n == 0:
+                continue                                  # full drain: nothing to count
+            count, i = 0, at - 1
+            while i > 0 and not (ins[i].startswith("buffer_load") and ins[i].rstrip().endswith(" lds")):
+                count += 1 if _VMEM.match(ins[i]) else 0
+                i -= 1
+            assert i > 0, (name[:70], b, "no LDS-DMA in front of a counted wait")
+            assert count >= n, (name[:70], f"barrier at {b}: vmcnt({n}) but only {count} VMEM operations follow the "
+                                           f"last weight-DMA piece (instruction {i}): the DMA may be in flight at the barrier")
+            if not any(x.startswith(("s_cbranch", "s_branch")) for x in ins[i:b]):
+                steady += 1
+        assert steady >= nch, (name[:70], steady)        # every chunk of the K loop was seen

@@ -35,7 +35,7 @@ def test_bench_takes_the_rccl_path_with_one_rank():
     assert torch.cuda.is_available()
     env = _env(LC_BENCH_FORCE_DIST=1, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
-                        "--repeat", "1", "--no-cpu-baseline", "--no-traffic"],
+                        "--repeat", "1", "--no-cpu-baseline", "--no-traffic", "--no-rows"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
@@ -43,7 +43,23 @@ def test_bench_takes_the_rccl_path_with_one_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 2 and d["value"] > 0
     assert d["config"]["parallelism"].startswith("dp1")
     assert d["verify"]["ok"] is True                     # the 50-step check against the reference fixture ran inside it
+    assert d["verify"]["ranks_verified"] == 1 and d["verify"]["per_rank"][0]["samples"] == [0, 7]
     assert d["config"].get("collectives") == "rccl: barrier + all_reduce(MAX) + all_gather of the frames executed"
+
+
+def test_bench_verifies_the_shard_of_any_rank():
+    """rank r of `bench.py --gpus N` checks ITS shard (global samples 8r..8r+7) against the
+    reference's run of those seeds -- the function every rank calls, here for rank 3 of 8 on the one GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    dev = torch.device("cuda:0")
+    ddpm, _ = bench.build_ddpm(dev)
+    res = bench.verify_against_reference(ddpm, 3, 8, dev)
+    assert res["ok"] is True and res["samples"] == [24, 31] and res["against"].endswith("c2_shards.npz"), res
+    assert 0 < res["max_rel_l2_per_sample"]["x50"] < 1e-3
+    x3 = bench.x_T_for(3, ddpm.sampling_shape, 8)
+    assert torch.equal(x3[2], torch.randn(*ddpm.sampling_shape, generator=torch.Generator().manual_seed(26)))
 
 
 def test_cli_under_torchrun_one_rank(tmp_path):
