@@ -400,6 +400,31 @@ int lc_gate_bias_act(const float* x, int64_t x_bs, const float* gate_logit, cons
                      int64_t gb_bs, const float* res, int64_t res_bs, float* y, int64_t y_bs,
                      int B, int C, int N, int act, lc_stream_t s);
 
+/* ---------------------------------------------------------------------------------------------
+ * Block.downsample of EfficientUNet folded: `ops.Conv2d(3x3, ring)` followed by `ops.Resample(down=2)`
+ * (lidargen/models/unets/efficient_unet.py:132-135; ops.py:52-146 FIR [1 3 3 1] / 8, ring along W, zero padding of the
+ * conv's OUTPUT along H; ops.py:149-173) evaluated as ONE stride-2 3x3 convolution of the FIR-pre-filtered input -- a quarter
+ * of the reference conv's multiply-adds and output bytes, no resampling pass (csrc/conv_f16x2_s2.hip has the algebra).
+ *
+ * lc_fir_down2_prefilter_split: x [B, C, H, W] fp32 (batch stride x_bs floats, channel stride H*W; C % 16 == 0, H even >= 4,
+ *   W % 128 == 0) -> y_split: the pre-filtered tensor F in the pre-split form of lc_groupnorm_apply_split (fp16 hi / lo
+ *   planes, 16-byte units of 8 channels, already multiplied by range->x_scale; max |F * x_scale| is published into *range),
+ *   per sample [2 planes][C / 8][H + 3 rows][W units]: rows 0 .. H = F[-1 .. H-1], row H + 1 / H + 2 = the top / bottom
+ *   boundary variants; inside a row the odd input columns first (unit i = column 2 i - 1, ring), then the even ones.
+ *   lc_fir_down2_split_units gives the number of 16-byte units of y_split.
+ * lc_conv2d_ring_s2_f16x2_ps_fwd: y [B, Co, Ho, Wo] = (stride-2 conv of F with the layer's packed 3x3 weights + bias) *
+ *   out_scale; Ho = H / 2, Wo = W / 2 (Wo % 64 == 0).  wp_hi / wp_lo / wmeta / range: as lc_conv2d_ring_f16x2_ps_fwd.
+ *   gn_ostats_out (optional): octet (unit 8) or quad (unit 4) GroupNorm statistics entries of what it stores,
+ *   [B][Co / unit][lc_conv2d_ring_s2_stats_slots(Ho, Wo)][4] floats. */
+int64_t lc_fir_down2_split_units(int B, int C, int H, int W);
+int lc_fir_down2_prefilter_split(const float* x, int64_t x_bs, void* y_split, int B, int C, int H, int W,
+                                 lc_conv_range* range, lc_stream_t s);
+int64_t lc_conv2d_ring_s2_stats_slots(int Ho, int Wo);
+int lc_conv2d_ring_s2_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias, float* y,
+                                   int64_t y_bs, int B, int Ci, int Co, int Ho, int Wo, float out_scale,
+                                   float* gn_ostats_out, int gn_ostats_unit, const float* wmeta, lc_conv_range* range,
+                                   lc_stream_t s);
+
 /* Box calibration for bench.py (`box_calibration`): what THIS box's matrix pipes and memory sustain, so that numbers of
  * different boxes of the pool can be compared.  No counterpart in the reference.
  * lc_calibrate_mfma_f16: `blocks` blocks of 8 waves run `iters` x 16 v_mfma_f32_32x32x16_f16 per wave on the caller's

@@ -102,6 +102,10 @@ SIGNATURES = {
     "lc_attention_bwd_f16x2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "lc_gate_bias_act": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "lc_fir_down2_split_units": (i64, [i32, i32, i32, i32]),
+    "lc_fir_down2_prefilter_split": (i32, [vp, i64, vp, i32, i32, i32, i32, vp, vp]),
+    "lc_conv2d_ring_s2_stats_slots": (i64, [i32, i32]),
+    "lc_conv2d_ring_s2_f16x2_ps_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp, vp]),
     "lc_calibrate_mfma_f16": (i64, [vp, i32, i32, vp, vp]),
     "lc_calibrate_stream_copy": (i32, [vp, vp, i64, vp]),
     "lc_copy_strided": (i32, [vp, i64, vp, i64, i32, i64, vp]),

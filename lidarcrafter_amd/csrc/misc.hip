@@ -222,6 +222,7 @@ int lc_touch_conv();
 int lc_touch_conv_bwd();
 int lc_touch_conv_f16x2();
 int lc_touch_conv_f16x2_tall();
+int lc_touch_conv_f16x2_s2();
 int lc_touch_geometry();
 int lc_touch_layout();
 int lc_touch_lidar();
@@ -233,7 +234,7 @@ int lc_touch_temporal();
 int lc_touch_voxel();
 }
 extern "C" int lc_load_code_objects(void) {
-    int (*const touch[])() = {lc_touch_attention, lc_touch_attention_bwd, lc_touch_attention_bwd_h, lc_touch_conv, lc_touch_conv_bwd, lc_touch_conv_f16x2, lc_touch_conv_f16x2_tall, lc_touch_geometry, lc_touch_layout, lc_touch_lidar, lc_touch_metrics, lc_touch_norm, lc_touch_resample, lc_touch_roipool, lc_touch_temporal, lc_touch_voxel};
+    int (*const touch[])() = {lc_touch_attention, lc_touch_attention_bwd, lc_touch_attention_bwd_h, lc_touch_conv, lc_touch_conv_bwd, lc_touch_conv_f16x2, lc_touch_conv_f16x2_tall, lc_touch_conv_f16x2_s2, lc_touch_geometry, lc_touch_layout, lc_touch_lidar, lc_touch_metrics, lc_touch_norm, lc_touch_resample, lc_touch_roipool, lc_touch_temporal, lc_touch_voxel};
     for (auto f : touch) {
         const int rc = f();
         if (rc != 0) return rc;

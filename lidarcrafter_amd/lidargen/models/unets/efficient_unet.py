@@ -150,7 +150,17 @@ class Block(nn.Module):
         has_attn = not isinstance(self.self_attn_block, nn.Identity)
         has_up = not isinstance(self.upsample, nn.Identity)
         if not isinstance(self.downsample, nn.Identity):
-            h = self.downsample[1](self.downsample[0](h))
+            conv, rs = self.downsample
+            B_, Ci_, H_, W_ = h.shape
+            if rs.down == 2 and conv.ring and K.can_fold_down(Ci_, conv.out_channels, H_, W_):
+                # conv at full resolution + FIR + decimation == stride-2 conv of the FIR-pre-filtered input: a quarter of the
+                # conv's multiply-adds and output bytes, no resampling pass (ops.conv_down2, csrc/conv_f16x2_s2.hip);
+                # it leaves the statistics entries the first residual block's GroupNorm can fold (octets, else quads)
+                cpg = conv.out_channels // self.residual_blocks[0].norm1.num_groups
+                unit = 8 if cpg % 8 == 0 else (4 if cpg % 4 == 0 else 0)
+                h = K.conv_down2(h, conv._packed, conv.weight, conv.bias, emit_stats=unit)
+            else:
+                h = rs(conv(h))
         n = len(self.residual_blocks)
         for i, rb in enumerate(self.residual_blocks):
             last = (i == n - 1) and not has_attn and not has_up

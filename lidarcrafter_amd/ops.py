@@ -1096,6 +1096,63 @@ def _conv2d_ring_presplit(xs: SplitAct, packed: PackedConv, weight, bias, res, o
     return out
 
 
+# ---- Block.downsample folded (round 6): Conv2d(3x3, ring) -> Resample(down=2) as ONE stride-2 conv behind a FIR pre-filter.
+# csrc/conv_f16x2_s2.hip has the algebra (both operators are linear; away from the H border they commute, and the two border
+# cases are handled by variant rows of the pre-filtered tensor + the bias factor 7/8).  LC_FOLD_DOWN=0: the reference's
+# order (conv at full resolution, then the resampling pass).
+FOLD_DOWN = _os.environ.get("LC_FOLD_DOWN", "1") != "0"
+
+
+def can_fold_down(Ci: int, Co: int, H: int, W: int) -> bool:
+    return (FOLD_DOWN and PRESPLIT and CONV_PRECISION == "f16x2" and conv_products() == 3 and Ci % 16 == 0 and
+            Co % 8 == 0 and H % 2 == 0 and H >= 4 and W % 128 == 0)
+
+
+def conv_down2(x: torch.Tensor, packed: PackedConv, weight, bias, out: Optional[torch.Tensor] = None,
+               emit_stats=False) -> torch.Tensor:
+    """y = Resample(down=2)(Conv2d_ring3x3(x) + bias) of the reference (efficient_unet.py:132-135, ops.py:52-173) for
+    x [B, Ci, H, W] -> [B, Co, H/2, W/2], computed as stride-2 conv(FIR-pre-filter(x)): lc_fir_down2_prefilter_split +
+    lc_conv2d_ring_s2_f16x2_ps_fwd.  emit_stats (True / 8 / 4): octet / quad GroupNorm statistics of the result."""
+    x_bs = _bs4(x, "x")
+    B, Ci, H, W = x.shape
+    wh, wl = packed.get_f16x2(weight)
+    Co = packed.Co
+    if packed.ks != 3 or Ci != packed.Ci or not can_fold_down(Ci, Co, H, W):
+        raise ValueError("conv_down2: needs a 3x3 layer with Ci % 16 == 0, H even >= 4, W % 128 == 0 (ops.can_fold_down)")
+    dev = x.device
+    Ho, Wo = H // 2, W // 2
+    if out is None:
+        out = torch.empty((B, Co, Ho, Wo), device=dev, dtype=_F32)
+    y_bs = _bs4(out, "out")
+    if tuple(out.shape) != (B, Co, Ho, Wo):
+        raise ValueError(f"conv_down2: out shape {tuple(out.shape)} != {(B, Co, Ho, Wo)}")
+    if bias is not None:
+        _req(bias, "bias")
+    _drop_stats(out)
+    units = int(lib().lc_fir_down2_split_units(B, Ci, H, W))
+    buf = torch.empty((units, 8), device=dev, dtype=torch.float16)
+    rng_ptr = packed.range_ptr(dev)
+    with _Timed("resample", 8.0 * B * Ci * H * W):
+        check(lib().lc_fir_down2_prefilter_split(x.data_ptr(), x_bs, buf.data_ptr(), B, Ci, H, W, rng_ptr, _stream()),
+              "lc_fir_down2_prefilter_split")
+    unit = 8 if emit_stats is True else int(emit_stats or 0)
+    sbuf, slots = None, 0
+    if unit in (8, 4) and PRODUCER_GN_STATS:
+        slots = int(lib().lc_conv2d_ring_s2_stats_slots(Ho, Wo))
+        if slots > 0:
+            sbuf = torch.empty((B, Co // unit, slots, 4), device=dev, dtype=_F32)
+    # (work = the multiply-adds this launch EXECUTES: a quarter of the reference conv's at full resolution)
+    with _Timed("conv3x3", 2.0 * B * Ho * Wo * Co * Ci * 9,
+                rd=4.0 * (B * Ci * (H + 3) * W + Co * Ci * 9), wr=4.0 * B * Co * Ho * Wo):
+        check(lib().lc_conv2d_ring_s2_f16x2_ps_fwd(buf.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), out.data_ptr(),
+                                                   y_bs, B, Ci, Co, Ho, Wo, 1.0, _p(sbuf), unit if sbuf is not None else 8,
+                                                   packed.wmeta.data_ptr(), rng_ptr, _stream()),
+              "lc_conv2d_ring_s2_f16x2_ps_fwd")
+    if sbuf is not None:
+        _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, Ho * Wo), unit))
+    return out
+
+
 # Split-K (pre-split conv): when a 3x3 conv has fewer than SPLITK_MAX_BLOCKS output tiles (batch
 # 1-2 at the deep levels), its K range is divided over several blocks per tile.
 SPLITK = _os.environ.get("LC_SPLITK", "1") != "0"

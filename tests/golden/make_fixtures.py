@@ -81,6 +81,22 @@ def sec_ops():
     save("ops", **out)
 
 
+def sec_fold_down():
+    """Block.downsample of the reference's EfficientUNet (efficient_unet.py:132-135): ops.Conv2d(3x3, ring) followed by
+    ops.Resample(down=2) -- the pair the HIP path evaluates as one stride-2 conv behind a FIR pre-filter
+    (lidarcrafter_amd/csrc/conv_f16x2_s2.hip).  Shapes: the image's top and bottom rows in one tile (H = 4), whole and
+    ragged 64-channel output blocks, an input with a mean (the bias / border factor 7/8 shows)."""
+    ops = R.ref("models.unets.ops")
+    out = {}
+    with torch.no_grad():
+        for tag, (B, Ci, Co, H, W, salt) in {"a": (2, 16, 32, 8, 128, 31), "b": (1, 32, 72, 4, 256, 32),
+                                             "c": (1, 64, 128, 16, 128, 33)}.items():
+            conv = seeded_fill(ops.Conv2d(Ci, Co, 3, 1, 1, ring=True), salt=salt)
+            x = seeded_randn(B, Ci, H, W, seed=300 + salt) + 0.3
+            out[f"{tag}_y"] = ops.Resample(down=2, ring=True)(conv(x))
+    save("fold_down", **out)
+
+
 def _build_uncond(eu, base, res):
     m = eu.EfficientUNet(2, res, base_channels=base, temb_channels=None,
                          channel_multiplier=(1, 2, 4, 8), num_residual_blocks=(3, 3, 3, 3),
