@@ -359,19 +359,25 @@ int lc_attention_f16x2_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
  * exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and writes dq, dk, dv (same shapes as q, k, v); deterministic (one
  * kernel with the queries as the outer dimension for dq, one with the keys for dk / dv; no atomics).
  * dsum_scratch: float [BH, Lq].  dqk, dv <= 64.
+ * qkv_amax (round 6; f16x2 = 1 only, may be NULL): 3 floats of scratch the caller keeps alive until the backward pass has
+ * run.  The forward measures max |q|, max |k|, max |v| into them on the device and both passes derive the powers of two
+ * their fp16 hi / lo operand splits use from those words (16 while max |x| * 16 lies in [2^2, 2^15): the results of
+ * rounds 1-5; otherwise the power of two that fits -- csrc/attention_pre.h).  NULL: the constant 16, which saturates
+ * |x| >= 4094 silently.
  * ------------------------------------------------------------------------------------------- */
 int lc_attention_train_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int BH, int Lq,
-                           int Lk, int dqk, int dv, float scale, int f16x2, lc_stream_t s);
+                           int Lk, int dqk, int dv, float scale, int f16x2, float* qkv_amax, lc_stream_t s);
 int lc_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout,
                      const float* lse, float* dsum_scratch, float* dq, float* dk, float* dv, int BH, int Lq, int Lk,
                      int dqk, int dv_ch, float scale, lc_stream_t s);
 /* The same backward pass with the f16x2-split arithmetic of lc_attention_f16x2_fwd (three v_mfma_f32_32x32x16_f16 per
  * product, fp32 accumulation; the default of lidarcrafter_amd.autograd).  The gradient dO may have any magnitude: its
  * maximum is measured next to D and the power of two that normalises it is carried exactly through dP, dS and the
- * outputs.  dsum_scratch: float [BH * Lq + 1] (the extra word holds max |dO|). */
+ * outputs.  dsum_scratch: float [BH * Lq + 1] (the extra word holds max |dO|).  qkv_amax: the words
+ * lc_attention_train_fwd measured for the same q, k, v (or NULL: constant pre-scale 16). */
 int lc_attention_bwd_f16x2(const float* q, const float* k, const float* v, const float* o, const float* dout,
                            const float* lse, float* dsum_scratch, float* dq, float* dk, float* dv, int BH, int Lq,
-                           int Lk, int dqk, int dv_ch, float scale, lc_stream_t s);
+                           int Lk, int dqk, int dv_ch, float scale, const float* qkv_amax, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse-diffusion update, one fused elementwise pass:

@@ -97,9 +97,9 @@ SIGNATURES = {
                                i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "lc_attention_f16x2_fwd": (i32, [_op, _op, _op, _op, _op, _op, _op, _op, vp, i64, i64, i64,
                                      i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
-    "lc_attention_train_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "lc_attention_train_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp]),
     "lc_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
-    "lc_attention_bwd_f16x2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "lc_attention_bwd_f16x2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
     "lc_pstep_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i64, i32, i32, vp]),
     "lc_gate_bias_act": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "lc_fir_down2_split_units": (i64, [i32, i32, i32, i32]),

@@ -255,12 +255,17 @@ class FlashAttention(torch.autograd.Function):
         Lk, dv = k.shape[-1], v.shape[2]
         o = torch.empty((B, h, dv, Lq), device=q.device, dtype=torch.float32)
         lse = torch.empty((B * h, Lq), device=q.device, dtype=torch.float32)
+        # max |q|, |k|, |v| measured on the device by the forward entry; both passes derive the pre-scales of their fp16
+        # operand splits from these three words (csrc/attention_pre.h): no host synchronisation, any operand magnitude
+        amax = torch.empty(3, device=q.device, dtype=torch.float32) if TRAIN_ATTN_FWD_PRECISION == "f16x2" else None
         with torch.cuda.device(q.device):
             check(lib().lc_attention_train_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(),
                                                B * h, Lq, Lk, dqk, dv, float(scale),
                                                1 if TRAIN_ATTN_FWD_PRECISION == "f16x2" else 0,
+                                               None if amax is None else amax.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream), "lc_attention_train_fwd")
         ctx.save_for_backward(q, k, v, o, lse)
+        ctx.qkv_amax = amax
         ctx.scale = float(scale)
         return o
 
@@ -272,11 +277,17 @@ class FlashAttention(torch.autograd.Function):
         Lk, dv = k.shape[-1], v.shape[2]
         dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         scratch = torch.empty(B * h * Lq + 1, device=q.device, dtype=torch.float32)
-        fn = lib().lc_attention_bwd_f16x2 if TRAIN_ATTN_BWD_PRECISION == "f16x2" else lib().lc_attention_bwd
         with torch.cuda.device(q.device):
-            check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-                     scratch.data_ptr(), dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), B * h, Lq, Lk, dqk, dv, ctx.scale,
-                     torch.cuda.current_stream().cuda_stream), "lc_attention_bwd")
+            st = torch.cuda.current_stream().cuda_stream
+            args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                    scratch.data_ptr(), dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), B * h, Lq, Lk, dqk, dv, ctx.scale)
+            if TRAIN_ATTN_BWD_PRECISION == "f16x2":
+                amax = ctx.qkv_amax
+                if amax is None:           # (exact-fp32 forward + split backward: measure here, same rule)
+                    amax = torch.stack([q.abs().amax(), k.abs().amax(), v.abs().amax()]).float()
+                check(lib().lc_attention_bwd_f16x2(*args, amax.data_ptr(), st), "lc_attention_bwd_f16x2")
+            else:
+                check(lib().lc_attention_bwd(*args, st), "lc_attention_bwd")
         return dq, dk, dvv, None
 
 

@@ -27,6 +27,7 @@ struct AttnArgs {
     int heads, Lq, Lk0, Lk1, dqk, dpos, dv;
     float qscale;  // scale * log2(e)
     float* lse;    // optional [B * heads, Lq]: log2-sum-exp of the scaled scores (base 2, qscale included) for the backward pass
+    const unsigned* qkv_amax;   // training entry (attn_h_kernel<..., PRE = true>): bit patterns of max |q|, |k|, |v| (attention_pre.h)
 };
 
 __device__ __forceinline__ const float* head_ptr(const lc_cm_operand& x, int b, int h) {
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+#include "attention_pre.h"
+
 constexpr float QK_PRE = 16.0f;      // q (after the softmax scale) and k are pre-scaled by 16
 constexpr float P_PRE = 2048.0f;     // p in [0,1]
 constexpr float P_LOG2 = 11.0f;      // log2(P_PRE)
@@ -203,7 +206,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& 
 // queries per block halve it per query, and the roles are dealt so that no wave splits more than one operand: waves
 // 0-3 stage K, waves 4-5 stage V, waves 6-7 only compute.  Bit-identical results; 2048 + 13 keys 241.8 -> 227.4 us,
 // 512 + 13 keys 45.6 -> 40.0, 512 keys 29.1 -> 25.0 (profiles/r05_level0.txt section 1).
-template <int DQK, int NDV, int NW = 4>
+// PRE (round 6, training entry only): the three pre-scales are derived from the measured maxima of q, k, v instead of the
+// constants -- the inference instantiations are unchanged.
+template <int DQK, int NDV, int NW = 4, bool PRE = false>
 __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
     constexpr int DV = NDV * 32;
     constexpr int NKU = DQK / 8 * 32;    // K units [cb][key]
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
     {
         const float* qc = head_ptr(a.q, b, h);
         const float* qpos = head_ptr(a.qp, b, h);
-        const float qs = a.qscale * QK_PRE;
+        const float qs = a.qscale * (PRE ? attn_pre_from(__uint_as_float(a.qkv_amax[0]) * fabsf(a.qscale)) : QK_PRE);
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             float v[8];
@@ -332,16 +337,18 @@ __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
             for (int m = 0; m < 8; ++m) vreg[m] = 0.f;
         }
     };
+    const float k_pre = PRE ? attn_pre_from(__uint_as_float(a.qkv_amax[1])) : QK_PRE;
+    const float v_pre = PRE ? attn_pre_from(__uint_as_float(a.qkv_amax[2])) : V_PRE;
     auto store_tile = [&]() {
         if (tid < NKU) {
             half8 hi, lo;
-            split8(kreg, QK_PRE, hi, lo);
+            split8(kreg, k_pre, hi, lo);
             k_hi[tid] = hi;                       // unit index = cb*32 + key = tid
             k_lo[tid] = lo;
         }
         if (v_role) {
             half8 hi, lo;
-            split8(vreg, V_PRE, hi, lo);
+            split8(vreg, v_pre, hi, lo);
             // keys 8o+0..3 -> (step o>>1, half 0), keys 8o+4..7 -> (step o>>1, half 1); both land
             // in the 4-element piece (o&1) of their unit
             const int u0 = ((v_o >> 1) * 2 + 0) * DV + v_c, u1 = u0 + DV;
@@ -356,7 +363,8 @@ __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
         }
     };
 
-    constexpr float S_UN = 1.0f / (QK_PRE * QK_PRE);
+    const float S_UN = PRE ? 1.0f / (attn_pre_from(__uint_as_float(a.qkv_amax[0]) * fabsf(a.qscale)) * k_pre)
+                           : 1.0f / (QK_PRE * QK_PRE);
     load_tile(0);
     for (int s0 = 0; s0 < Lk; s0 += 32) {
         __syncthreads();   // previous tile fully consumed
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / (l_tot * V_PRE);
+    const float inv = 1.0f / (l_tot * v_pre);
     float* op = a.o + b * a.o_bs + h * a.o_hs;
     if (a.lse && t < a.Lq && kh == 0) a.lse[(long long)bh * a.Lq + t] = m_run + log2f(l_tot) - P_LOG2;   // (l_run carries P_PRE)
     if (t < a.Lq) {
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(64 * NW) void attn_h_kernel(AttnArgs a) {
 
 }  // namespace
 
-static int attention_launch(int split, float* lse, const lc_cm_operand* q, const lc_cm_operand* q_pos,
+static int attention_launch(int split, float* lse, const unsigned* qkv_amax, const lc_cm_operand* q, const lc_cm_operand* q_pos,
                                 const lc_cm_operand* k, const lc_cm_operand* k_pos,
                                 const lc_cm_operand* v, const lc_cm_operand* k2,
                                 const lc_cm_operand* k2_pos, const lc_cm_operand* v2, float* o,
@@ -464,6 +472,7 @@ static int attention_launch(int split, float* lse, const lc_cm_operand* q, const
     a.heads = heads; a.Lq = Lq; a.Lk0 = Lk0; a.Lk1 = Lk1; a.dqk = dqk; a.dpos = dpos; a.dv = dv;
     a.qscale = scale * 1.4426950408889634f;
     a.lse = lse;
+    a.qkv_amax = qkv_amax;
     dim3 grid((Lq + 127) / 128, B * heads);
     const int dq = (dqk + dpos) <= 32 ? 32 : 64, nd = dv <= 32 ? 1 : 2;
     if (split && dqk % 8 == 0) {   // (a K unit = 8 channels of ONE operand; else the fp32 kernel)
@@ -471,6 +480,13 @@ static int attention_launch(int split, float* lse, const lc_cm_operand* q, const
         // of the layout model and the 512-key self-attention gain 6-14 %; a 300-token batch-2 case loses 12 %)
         static const int w8_env = [] { const char* e = getenv("LC_ATTN_WAVES"); return e ? atoi(e) : 0; }();
         const long long blocks8 = (long long)((Lq + 255) / 256) * B * heads;
+        if (qkv_amax) {            // training entry: measured pre-scales
+            if (dq == 32 && nd == 1) hipLaunchKernelGGL((attn_h_kernel<32, 1, 4, true>), grid, dim3(256), 0, lc_s(s), a);
+            else if (dq == 64 && nd == 1) hipLaunchKernelGGL((attn_h_kernel<64, 1, 4, true>), grid, dim3(256), 0, lc_s(s), a);
+            else if (dq == 32 && nd == 2) hipLaunchKernelGGL((attn_h_kernel<32, 2, 4, true>), grid, dim3(256), 0, lc_s(s), a);
+            else hipLaunchKernelGGL((attn_h_kernel<64, 2, 4, true>), grid, dim3(256), 0, lc_s(s), a);
+            return lc_launch_status();
+        }
         if (nd == 1 && (w8_env == 8 || (w8_env == 0 && blocks8 >= 128))) {
             dim3 grid8((Lq + 255) / 256, B * heads);
             if (dq == 32) hipLaunchKernelGGL((attn_h_kernel<32, 1, 8>), grid8, dim3(512), 0, lc_s(s), a);
@@ -500,15 +516,27 @@ static int attention_launch(int split, float* lse, const lc_cm_operand* q, const
     q, q_pos, k, k_pos, v, k2, k2_pos, v2, o, o_bs, o_hs, o_cs, B, heads, Lq, Lk0, Lk1, dqk,     \
         dpos, dv, scale, s
 
-extern "C" int lc_attention_fwd(LC_ATTN_PARAMS) { return attention_launch(0, nullptr, LC_ATTN_ARGS); }
-extern "C" int lc_attention_f16x2_fwd(LC_ATTN_PARAMS) { return attention_launch(1, nullptr, LC_ATTN_ARGS); }
+extern "C" int lc_attention_fwd(LC_ATTN_PARAMS) { return attention_launch(0, nullptr, nullptr, LC_ATTN_ARGS); }
+extern "C" int lc_attention_f16x2_fwd(LC_ATTN_PARAMS) { return attention_launch(1, nullptr, nullptr, LC_ATTN_ARGS); }
 // Training forward: the same kernels, plus the per-query log2-sum-exp the backward pass recomputes P from
+// (qkv_amax: 3 words of scratch that stay alive until the backward pass has run -- the forward measures max |q|, |k|, |v| into
+//  them and both passes derive their operand pre-scales from them, attention_pre.h; NULL: the constant pre-scale 16)
 extern "C" int lc_attention_train_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int BH,
-                                      int Lq, int Lk, int dqk, int dv, float scale, int f16x2, lc_stream_t s) {
+                                      int Lq, int Lk, int dqk, int dv, float scale, int f16x2, float* qkv_amax,
+                                      lc_stream_t s) {
     if (!q || !k || !v || !o || !lse || BH <= 0) return LC_EINVAL;
+    unsigned* am = reinterpret_cast<unsigned*>(qkv_amax);
+    if (am && f16x2) {
+        if (hipMemsetAsync(am, 0, 3 * sizeof(unsigned), lc_s(s)) != hipSuccess) return lc_launch_status();
+        const long long nq = (long long)BH * dqk * Lq, nk = (long long)BH * dqk * Lk, nv = (long long)BH * dv * Lk;
+        const long long nmax = nq > nk ? (nq > nv ? nq : nv) : (nk > nv ? nk : nv);
+        long long g = (nmax / 4 + 255) / 256;
+        g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        hipLaunchKernelGGL(attn_amax3_kernel, dim3((unsigned)g, 3), dim3(256), 0, lc_s(s), q, nq, k, nk, v, nv, am);
+    }
     const lc_cm_operand oq = {q, (int64_t)dqk * Lq, 0, Lq}, ok = {k, (int64_t)dqk * Lk, 0, Lk}, ov = {v, (int64_t)dv * Lk, 0, Lk};
-    return attention_launch(f16x2, lse, &oq, nullptr, &ok, nullptr, &ov, nullptr, nullptr, nullptr, o, (int64_t)dv * Lq, 0, Lq,
-                            BH, 1, Lq, Lk, 0, dqk, 0, dv, scale, s);
+    return attention_launch(f16x2, lse, f16x2 ? am : nullptr, &oq, nullptr, &ok, nullptr, &ov, nullptr, nullptr, nullptr, o,
+                            (int64_t)dv * Lq, 0, Lq, BH, 1, Lq, Lk, 0, dqk, 0, dv, scale, s);
 }
 
 LC_TOUCH_TU(attention, attn_kernel<32, 1>)

@@ -13,8 +13,9 @@
 //     S^T = K_c Q, dP^T = V_c dO, dS^T = scale P (dP - D) in registers, dQ^T += K_p dS^T
 // dK/dV kernel (block = 4 waves x 32 keys; per 32-query tile: Q_c, Q_p, dO_c, dO_p, lse, D staged):
 //     S = Q_c K, dV^T += dO_p P, dP = dO_c V, dK^T += Q_p dS
-// Ranges: q, k, v are activations of a normalised network (pre-scale 16 / 16, as in the forward); dO is a gradient of
-// arbitrary magnitude: attn_dsum_h_kernel measures max |dO| next to D and every block derives the power of two that puts
+// Ranges: q, k, v take the pre-scales the forward pass used -- derived from max |q|, |k|, |v| as measured by the forward
+// entry (attention_pre.h: 16 for activations of a normalised network, a power of two that fits otherwise; round 6, before:
+// the constant 16, which saturated |x| >= 4094 silently); dO is a gradient of arbitrary magnitude: attn_dsum_h_kernel measures max |dO| next to D and every block derives the power of two that puts
 // it at 2^6, so dP, dS and the outputs carry that factor exactly until the epilogue divides it out.
 #include "common.h"
 
@@ -23,12 +24,14 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr float QK_PRE = 16.0f, V_PRE = 16.0f, P_PRE = 2048.0f;
-constexpr float S_UN = 1.0f / (QK_PRE * QK_PRE);
+#include "attention_pre.h"
+
+constexpr float P_PRE = 2048.0f;
 
 struct AttnBwdHArgs {
     const float *q, *k, *v, *dout, *lse, *dsum;
     const unsigned* do_amax;     // bit pattern of max |dO| (attn_dsum_h_kernel)
+    const unsigned* qkv_amax;    // bit patterns of max |q|, |k|, |v| (the forward entry's measurement), or NULL: pre-scale 16
     float *dq, *dk, *dv;
     int Lq, Lk, dqk, dv_;
     float qscale, scale;
@@ -133,12 +136,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_h_kernel(AttnBwdHArgs a) {
     const float* vb = a.v + bh * a.dv_ * a.Lk;
     const float* dob = a.dout + bh * a.dv_ * a.Lq;
     const float sdo = do_scale_from(*a.do_amax);
+    // operand pre-scales (q carries the softmax scale here: its maximum is taken after that factor)
+    const float QP = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[0]) * fabsf(a.qscale)) : 16.0f;
+    const float KP = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[1])) : 16.0f;
+    const float VP = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[2])) : 16.0f;
+    const float S_UN = 1.0f / (QP * KP);
     half8 qh[NST], ql[NST], doh[NSV], dol[NSV];
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
         float v[8];
         load_cunit(v, qb, a.Lq, a.dqk, 2 * st + kh, t, tok);
-        split8(v, a.qscale * QK_PRE, qh[st], ql[st]);
+        split8(v, a.qscale * QP, qh[st], ql[st]);
     }
 #pragma unroll
     for (int st = 0; st < NSV; ++st) {
@@ -147,7 +155,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_h_kernel(AttnBwdHArgs a) {
         split8(v, sdo, doh[st], dol[st]);
     }
     const float lse_t = tok ? a.lse[bh * a.Lq + t] : 0.f;
-    const float d_t = tok ? a.dsum[bh * a.Lq + t] * sdo : 0.f;
+    const float VP_ = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[2])) : 16.0f;
+    const float d_t = tok ? a.dsum[bh * a.Lq + t] * sdo * (VP_ == 16.0f ? 1.0f : VP_ * (1.0f / 128.0f)) : 0.f;
     f32x16 dqacc[NDQ];
 #pragma unroll
     for (int i = 0; i < NDQ; ++i)
@@ -164,11 +173,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_h_kernel(AttnBwdHArgs a) {
         load_cunit(rvc, vb, a.Lk, a.dv_, c_cb, s0 + c_pos, tid < NVC);
     };
     auto store_tile = [&]() {
-        if (tid < NKC) { half8 hi, lo; split8(rkc, QK_PRE, hi, lo); kc_hi[tid] = hi; kc_lo[tid] = lo; }
-        if (tid < NKP) store_poct<DQK>(kp_hi, kp_lo, rkp, QK_PRE, p_c, p_o);
-        if (tid < NVC) { half8 hi, lo; split8(rvc, V_PRE, hi, lo); vc_hi[tid] = hi; vc_lo[tid] = lo; }
+        if (tid < NKC) { half8 hi, lo; split8(rkc, KP, hi, lo); kc_hi[tid] = hi; kc_lo[tid] = lo; }
+        if (tid < NKP) store_poct<DQK>(kp_hi, kp_lo, rkp, KP, p_c, p_o);
+        if (tid < NVC) { half8 hi, lo; split8(rvc, VP, hi, lo); vc_hi[tid] = hi; vc_lo[tid] = lo; }
     };
-    const float c2 = 1.0f / V_PRE;                      // dP' = V_PRE * sdo * dP
+    // dS = scale P (dP - D) grows with |v|: away from the default window it is carried times DS = VP / 128 (as if max |v|
+    // were ~16), so that its fp16 split neither saturates (|v| ~ 3e4) nor loses its lo half (|v| ~ 2e-5); 1 by default
+    const float DS = VP == 16.0f ? 1.0f : VP * (1.0f / 128.0f);
+    const float c2 = DS / VP;                           // dP' = VP * sdo * dP
     load_tile(0);
     for (int s0 = 0; s0 < a.Lk; s0 += 32) {
         __syncthreads();
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_h_kernel(AttnBwdHArgs a) {
         }
     }
     if (tok) {
-        const float un = 1.0f / (QK_PRE * sdo);
+        const float un = 1.0f / (KP * sdo * DS);
         float* dqb = a.dq + bh * a.dqk * a.Lq;
 #pragma unroll
         for (int i = 0; i < NDQ; ++i)
@@ -231,18 +243,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_h_kernel(AttnBwdHArgs a) {
     const float* vb = a.v + bh * a.dv_ * a.Lk;
     const float* dob = a.dout + bh * a.dv_ * a.Lq;
     const float sdo = do_scale_from(*a.do_amax);
+    const float QP = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[0])) : 16.0f;   // (q without the softmax scale here)
+    const float KP = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[1])) : 16.0f;
+    const float VP = a.qkv_amax ? attn_pre_from(__uint_as_float(a.qkv_amax[2])) : 16.0f;
+    const float DS = VP == 16.0f ? 1.0f : VP * (1.0f / 128.0f);     // dS is carried times DS (see the dQ kernel)
     half8 kh_[NST], kl_[NST], vh_[NSV], vl_[NSV];
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
         float v[8];
         load_cunit(v, kb, a.Lk, a.dqk, 2 * st + kh, s, sok);
-        split8(v, QK_PRE, kh_[st], kl_[st]);
+        split8(v, KP, kh_[st], kl_[st]);
     }
 #pragma unroll
     for (int st = 0; st < NSV; ++st) {
         float v[8];
         load_cunit(v, vb, a.Lk, a.dv_, 2 * st + kh, s, sok);
-        split8(v, V_PRE, vh_[st], vl_[st]);
+        split8(v, VP, vh_[st], vl_[st]);
     }
     f32x16 dkacc[NDQ], dvacc[NDV];
 #pragma unroll
@@ -269,13 +285,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_h_kernel(AttnBwdHArgs a) {
         }
     };
     auto store_tile = [&]() {
-        if (tid < NQC) { half8 hi, lo; split8(rqc, QK_PRE, hi, lo); qc_hi[tid] = hi; qc_lo[tid] = lo; }
-        if (tid < NQP) store_poct<DQK>(qp_hi, qp_lo, rqp, QK_PRE, p_c, p_o);
+        if (tid < NQC) { half8 hi, lo; split8(rqc, QP, hi, lo); qc_hi[tid] = hi; qc_lo[tid] = lo; }
+        if (tid < NQP) store_poct<DQK>(qp_hi, qp_lo, rqp, QP, p_c, p_o);
         if (tid < NDC) { half8 hi, lo; split8(rdc, sdo, hi, lo); dc_hi[tid] = hi; dc_lo[tid] = lo; }
         if (tid < NDP) store_poct<DV>(dp_hi, dp_lo, rdp, sdo, p_c, p_o);
-        if (tid < 32) { lse_s[tid] = rl; d_s[tid] = rd * sdo; }
+        if (tid < 32) { lse_s[tid] = rl; d_s[tid] = rd * sdo * DS; }
     };
-    const float c1 = a.qscale * S_UN, c2 = 1.0f / V_PRE;
+    const float c1 = a.qscale / (QP * KP), c2 = DS / VP;
     load_tile(0);
     for (int t0 = 0; t0 < a.Lq; t0 += 32) {
         __syncthreads();
@@ -312,12 +328,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_h_kernel(AttnBwdHArgs a) {
             for (int j = 0; j < 8; ++j) v[j] = ds[8 * st + j];
             split8(v, 1.0f, bh_, bl_);
 #pragma unroll
-            for (int i = 0; i < NDQ; ++i)     // dK^T += Q_p dS   (x QK_PRE x sdo)
+            for (int i = 0; i < NDQ; ++i)     // dK^T += Q_p dS   (x QP x sdo)
                 LC_MFMA3(dkacc[i], qp_hi[(st * 2 + kh) * DQK + i * 32 + l31], qp_lo[(st * 2 + kh) * DQK + i * 32 + l31], bh_, bl_);
         }
     }
     if (sok) {
-        const float unk = 1.0f / (QK_PRE * sdo), unv = 1.0f / (P_PRE * sdo);
+        const float unk = 1.0f / (QP * sdo * DS), unv = 1.0f / (P_PRE * sdo);
         float* dkb = a.dk + bh * a.dqk * a.Lk;
         float* dvb = a.dv + bh * a.dv_ * a.Lk;
 #pragma unroll
@@ -341,15 +357,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_h_kernel(AttnBwdHArgs a) {
 }  // namespace
 
 // dsum_scratch: float [BH * Lq + 1]: D per (head, query) and, in the last word, the bit pattern of max |dO|
+// qkv_amax: the 3 words the forward entry (lc_attention_train_fwd) measured, or NULL (constant pre-scale 16)
 extern "C" int lc_attention_bwd_f16x2(const float* q, const float* k, const float* v, const float* o, const float* dout,
                                       const float* lse, float* dsum_scratch, float* dq, float* dk, float* dv, int BH,
-                                      int Lq, int Lk, int dqk, int dv_ch, float scale, lc_stream_t s) {
+                                      int Lq, int Lk, int dqk, int dv_ch, float scale, const float* qkv_amax, lc_stream_t s) {
     if (!q || !k || !v || !o || !dout || !lse || !dsum_scratch || !dq || !dk || !dv || BH <= 0 || Lq <= 0 || Lk <= 0)
         return LC_EINVAL;
     if (dqk <= 0 || dqk > 64 || dv_ch <= 0 || dv_ch > 64) return LC_EUNSUP;
     AttnBwdHArgs a;
     unsigned* amax = reinterpret_cast<unsigned*>(dsum_scratch + (long long)BH * Lq);
     a.q = q; a.k = k; a.v = v; a.dout = dout; a.lse = lse; a.dsum = dsum_scratch; a.do_amax = amax;
+    a.qkv_amax = reinterpret_cast<const unsigned*>(qkv_amax);
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.Lq = Lq; a.Lk = Lk; a.dqk = dqk; a.dv_ = dv_ch;
     a.scale = scale; a.qscale = scale * 1.4426950408889634f;
