@@ -253,14 +253,38 @@ def box_calibration(device, seconds: float = 0.2):
         e1.record()
         e1.synchronize()
         tc = e0.elapsed_time(e1) * 1e-3 / reps
+    # the same MFMA loop in launches of ~50 us, each followed by a 32 MiB -> 32 MiB copy (~15 us): the duty cycle of the
+    # denoising step (matrix-bound launches between memory-bound passes) -- the chip's power management gives short bursts
+    # more clock than the long launches above
+    it_s = max(50, int(iters * 50e-6 / max(t, 1e-9)))
+    m = 1 << 23
+
+    def loop(with_mfma, nl=100):
+        e0.record()
+        fl_ = 0
+        for _ in range(nl):
+            if with_mfma:
+                fl_ += L.lc_calibrate_mfma_f16(ops.data_ptr(), blocks, it_s, sink.data_ptr(), st)
+            L.lc_calibrate_stream_copy(src.data_ptr(), dst.data_ptr(), m, st)
+        e1.record()
+        e1.synchronize()
+        return fl_, e0.elapsed_time(e1) * 1e-3
+
+    loop(True, 10)
+    fl_b, t_both = loop(True)
+    _, t_copy = loop(False)
+    burst = fl_b / max(t_both - t_copy, 1e-9) / 1e12
     del src, dst
     mf = sorted(rates)[len(rates) // 2]
+    best = max(mf, burst)
     return {"mfma_f16_tflops_random_operands": round(mf, 1),
-            "three_product_ceiling_tflops": round(mf / 3, 1),
+            "mfma_f16_tflops_random_operands_short_launches": round(burst, 1),
+            "three_product_ceiling_tflops": round(best / 3, 1),
             "stream_copy_tb_s": round(2 * 4 * n / tc / 1e12, 3),
-            "how": f"lc_calibrate_mfma_f16: {blocks} blocks x 8 waves, 4 accumulators, {iters} x 16 MFMAs per wave, "
-                   f"median of 4 launches; lc_calibrate_stream_copy: 1 GiB -> 1 GiB float4 copy, read + write bytes, "
-                   f"{reps} launches"}
+            "how": f"lc_calibrate_mfma_f16: {blocks} blocks x 8 waves, 4 accumulators; long launches: {iters} x 16 MFMAs per "
+                   f"wave, median of 4; short launches: 100 x ({it_s} x 16 MFMAs per wave + a 32 MiB copy), copy-only loop "
+                   f"subtracted; ceiling = the larger of the two / 3 products; lc_calibrate_stream_copy: 1 GiB -> 1 GiB "
+                   f"float4 copy, read + write bytes, {reps} launches"}
 
 
 def extra_rows(device, steps_small: int = 20):
@@ -468,14 +492,15 @@ def main():
         torch.cuda.synchronize()
         rec, K.PROFILE = K.PROFILE, None
         fam = {}
-        for name, work, e0, e1, rd, wr in rec:
-            a = fam.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
+        for name, work, e0, e1, rd, wr, executed in rec:
+            a = fam.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0, 0.0])
             a[0] += work
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
             a[3] += rd
             a[4] += wr
-        w, t, n, alg_rd, alg_wr = fam["conv3x3"]
+            a[5] += executed
+        w, t, n, alg_rd, alg_wr, w_exec = fam["conv3x3"]
         achieved = w / t / 1e12
         split = K.CONV_PRECISION == "f16x2"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
@@ -519,6 +544,10 @@ def main():
                 "launches_per_step": n // n_prof,
                 "avg_launch_us": round(t / n * 1e6, 1),
                 "flop_per_launch": round(w / n),
+                # the three down-sampling convs are evaluated as stride-2 convs of the FIR-pre-filtered input (a quarter of
+                # the reference conv's multiply-adds): `achieved` counts the reference's algorithmic flops, these two what the
+                # launches issue
+                "achieved_executed": round(w_exec / t / 1e12, 2), "frac_executed": round(w_exec / t / 1e12 / peak, 4),
                 "time_share_per_family_ms_per_step": {
                     k: round(v[1] / n_prof * 1e3, 3) for k, v in sorted(fam.items())}}
     if dist_on:
