@@ -106,10 +106,6 @@ def test_c2_other_shards_golden(dev, golden, c2_ddpm, shard):
     """What rank r > 0 of `bench.py --gpus N` computes: the 50-step DDIM run of global samples
     8 r ... 8 r + 7 against the reference's own run of those seeds (c2_shards.npz; bench.py checks
     every rank's shard against the same file)."""
-    import os
-
-    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "c2_shards.npz")):
-        pytest.skip("tests/golden/c2_shards.npz not generated (make_fixtures.py c2_shards: ~3 h of reference CPU time)")
     g = golden("c2_shards")
     rng = [torch.Generator().manual_seed(8 * shard + i) for i in range(8)]
     x = c2_ddpm.sample(8, 50, progress=False, rng=rng, mode="ddim")

@@ -50,8 +50,6 @@ def test_bench_takes_the_rccl_path_with_one_rank():
 def test_bench_verifies_the_shard_of_any_rank():
     """rank r of `bench.py --gpus N` checks ITS shard (global samples 8r..8r+7) against the
     reference's run of those seeds -- the function every rank calls, here for rank 3 of 8 on the one GPU."""
-    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "c2_shards.npz")):
-        pytest.skip("tests/golden/c2_shards.npz not generated (make_fixtures.py c2_shards)")
     sys.path.insert(0, ROOT)
     import bench
 
