@@ -127,7 +127,7 @@ def measure_hbm_traffic(timeout_s: int = 150):
             out = os.path.join(tmp, counter)
             cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p",
                    "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
-                   "--repeat", "1", "--no-verify", "--no-cpu-baseline", "--no-roofline"]
+                   "--repeat", "1", "--no-verify", "--no-cpu-baseline", "--no-roofline", "--no-rows"]
             env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                timeout=timeout_s)

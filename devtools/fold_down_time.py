@@ -47,9 +47,11 @@ def main():
             rec, K.PROFILE = K.PROFILE, None
             tp = sum(e0.elapsed_time(e1) for n_, _, e0, e1, *_ in rec if n_ == "resample") * 1e3 / 20
             tc = sum(e0.elapsed_time(e1) for n_, _, e0, e1, *_ in rec if n_ == "conv3x3") * 1e3 / 20
+        import hashlib
+        digest = hashlib.sha1(b.cpu().numpy().tobytes()).hexdigest()[:12]
         gf = 2.0 * B * (H // 2) * (W // 2) * Co * Ci * 9 / 1e9
         print(f"B={B} {Ci}->{Co} @ {H}x{W}: conv {t_conv:.1f} + down {t_down:.1f} = {t_old:.1f} us | folded {t_new:.1f} us "
-              f"(pre-filter {tp:.1f}, stride-2 conv {tc:.1f} = {gf / tc * 1e3:.0f} TFLOP/s executed) | rel-L2 {r:.2e}", flush=True)
+              f"(pre-filter {tp:.1f}, stride-2 conv {tc:.1f} = {gf / tc * 1e3:.0f} TFLOP/s executed) | rel-L2 {r:.2e} sha1 {digest}", flush=True)
 
 
 if __name__ == "__main__":

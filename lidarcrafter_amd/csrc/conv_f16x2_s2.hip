@@ -130,6 +130,240 @@ __global__ __launch_bounds__(256) void fir_down2_prefilter_split_kernel(
     publish_amax(range, am, seen);
 }
 
+using S2Cfg_ = HCfg<2, 2, 1, 1, 1, 64, 3>;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The stride-2 conv, second form (round 6, second half): WEIGHTS SHARED ACROSS THE BLOCK'S TILES.
+// The first form (conv_f16x2_ps_kernel<S2Cfg, EMIT, S2 = true>) is bound by its LDS-DMA traffic: 62 KB per 16-channel chunk
+// of a 64 co x 64 px tile, 58 % of it weights -- and a persistent block re-loads the SAME weight chunk for every one of its
+// tiles.  Here the block keeps the accumulators of all its TPB tiles (16 registers each) and runs the chunk loop OUTSIDE the
+// tile loop: weight chunk c travels once per block, the x image of (tile t, chunk c) once per (t, c) as before.  Per
+// (tile, chunk) iteration 26 KB of x + 37 / TPB KB of weights instead of 63.5 KB: -44 % at TPB = 4.  Same tile (64 co x
+// 1 x 64 px, 4 waves), same LDS image, fragment addressing, border variants and epilogue as the first form; the x buffers
+// ping-pong per iteration, the weight buffers per chunk.  Results are bit-identical to the first form (same products in the
+// same order per accumulator).
+template <int TPB, bool EMIT_STATS>
+__global__ __launch_bounds__(256, 1) void conv_s2_shared_w_kernel(ConvArgsH a) {
+    using C = S2Cfg_;
+    constexpr int CB = 2, NTAP = 9, BN = 64, TW = 64;
+    constexpr int XW = 2 * TW + 1, XR = 3, XU = CB * XR * XW, WU = NTAP * CB * BN;
+    constexpr int NWV = 4;
+    constexpr int NXI = (XU + 63) / 64, NWI = (WU + 63) / 64;
+    constexpr int XS = NXI * 64, WS = NWI * 64;
+    constexpr int KX = (2 * NXI + NWV - 1) / NWV, KW = (2 * NWI + NWV - 1) / NWV;     // DMA slots per wave: x 7, weights 9
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ half8 xlds[2][2 * XS];
+    __shared__ half8 wlds[2][2 * WS];
+    __shared__ half8 dummy[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wpx = wave & 1;
+    const int kh = lane >> 5, l31 = lane & 31;
+
+    int bx = blockIdx.x;
+    if (a.xcd) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+    const int gh_ = a.tiles_h / TPB;
+    const int tw_i = bx % a.tiles_w; bx /= a.tiles_w;
+    const int h0 = (bx % gh_) * TPB; bx /= gh_;
+    const int b = bx;
+    const int w0 = tw_i * TW;
+    const int co0 = blockIdx.y * BN;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int C8 = a.xsp_c8;
+    const int XROWS = 2 * H + 3, XCOLS = 2 * W;
+    const float out_unscale = a.range->x_unscale * a.wmeta[1];
+
+    const unsigned xbytes = 2u * (unsigned)C8 * (unsigned)(XROWS * XCOLS) * 16u;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xsp + (long long)b * a.xsp_bs), 0, xbytes, 0x00020000);
+    const unsigned wplane = (unsigned)(NTAP * a.Cib) * (unsigned)a.Cop;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, 2u * wplane * 16u, 0x00020000);
+
+    // x slots: per-lane source offsets of every tile (the row part differs per tile; the variants only at the image border)
+    unsigned vx[TPB][KX];
+    int lx[KX];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int j = wave + k * NWV;
+        const int plane = j / NXI, e = (j - plane * NXI) * 64 + lane;
+        const int cb = e / (XR * XW), rem = e - cb * (XR * XW);
+        const int ky = rem / XW, c = rem - ky * XW;
+        int col;
+        if (c <= TW) { col = w0 + c; col = col >= W ? col - W : col; }        // odd phase, ring
+        else col = W + w0 + (c - TW - 1);                                      // even phase
+        lx[k] = j < 2 * NXI ? plane * XS + (j - plane * NXI) * 64 : -1;
+#pragma unroll
+        for (int t = 0; t < TPB; ++t) {
+            const int oy = h0 + t;
+            int row = 2 * oy + ky;
+            if (oy == 0 && ky == 2) row = 2 * H + 1;
+            if (oy == H - 1 && ky == 0) row = 2 * H + 2;
+            const bool ok = j < 2 * NXI && e < XU && oy < H;
+            vx[t][k] = ok ? (unsigned)(((plane * C8 + cb) * XROWS + row) * XCOLS + col) * 16u : OOB;
+        }
+    }
+    unsigned vw[KW];
+    int lw[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int j = wave + k * NWV;
+        const int plane = j / NWI, e = (j - plane * NWI) * 64 + lane;
+        const int row = e / BN, cu = e - row * BN;
+        const int tap = row / CB, cb = row - tap * CB;
+        lw[k] = j < 2 * NWI ? plane * WS + (j - plane * NWI) * 64 : -1;
+        vw[k] = (j < 2 * NWI && e < WU) ? ((unsigned)((tap * a.Cib + cb) * a.Cop + co0 + cu) + plane * wplane) * 16u : OOB;
+    }
+    const unsigned x_chunk = (unsigned)CB * (unsigned)(XROWS * XCOLS) * 16u;
+    const unsigned w_chunk = (unsigned)CB * (unsigned)a.Cop * 16u;
+    auto dma_x = [&](int buf, int t, int k, int ch) {
+        half8* dst = lx[k] >= 0 ? &xlds[buf][lx[k]] : dummy;
+        lds_dma16(rs_x, (lds_vptr)dst, vx[t][k], (unsigned)ch * x_chunk);
+    };
+    auto dma_w = [&](int buf, int k, int ch) {
+        half8* dst = lw[k] >= 0 ? &wlds[buf][lw[k]] : dummy;
+        lds_dma16(rs_w, (lds_vptr)dst, vw[k], (unsigned)ch * w_chunk);
+    };
+
+    f32x16 acc[TPB];
+#pragma unroll
+    for (int t = 0; t < TPB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int xbase = kh * (XR * XW) + wpx * 32 + l31;
+    const int wbase = kh * BN + wco * 32 + l31;
+
+    // one (tile, chunk) iteration: MFMAs of tile T from xlds[xb] / wlds[wb]; the NEXT iteration's x image (tile NT, chunk nch)
+    // is DMA'd into xlds[xb ^ 1] under them and, when NEXTW, weight chunk nch into wlds[wb ^ 1]
+    auto iteration = [&](auto T_, auto NT_, auto NEXTW_, int xb, int wb, int nch, bool issue_next) {
+        constexpr int T = decltype(T_)::value, NT = decltype(NT_)::value;
+        constexpr bool NEXTW = decltype(NEXTW_)::value;
+        constexpr int NSLOT = KX + (NEXTW ? KW : 0);
+        constexpr int SPT = (NSLOT + NTAP - 1) / NTAP;
+        const half8* cxh = &xlds[xb][0];
+        const half8* cxl = cxh + XS;
+        const half8* cwh = &wlds[wb][0];
+        const half8* cwl = cwh + WS;
+        half8 ah[2], al[2], bh[2], bl[2];
+        auto fetch = [&](int tap, int s) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int o = dy * XW + (dx == 1 ? TW + 1 : (dx == 2 ? 1 : 0));
+            ah[s] = cwh[tap * CB * BN + wbase];
+            al[s] = cwl[tap * CB * BN + wbase];
+            bh[s] = cxh[xbase + o];
+            bl[s] = cxl[xbase + o];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int s = tap & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < NTAP) fetch(tap + 1, s ^ 1);
+            if (issue_next) {
+#pragma unroll
+                for (int q = 0; q < SPT; ++q) {
+                    const int k = tap * SPT + q;
+                    if (k < KX) dma_x(xb ^ 1, NT, k, nch);
+                    else if (NEXTW && k < NSLOT) dma_w(wb ^ 1, k - KX, nch);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (LC_F16X2_TERMS & 2) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], bh[s], acc[T], 0, 0, 0);
+            if (LC_F16X2_TERMS & 4) acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bl[s], acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], bh[s], acc[T], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // prologue: x(tile 0, chunk 0) and weight chunk 0
+#pragma unroll
+    for (int k = 0; k < KX; ++k) dma_x(0, 0, k, 0);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) dma_w(0, k, 0);
+    const int co_wave = co0 + wco * 32 + 4 * kh;
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co_wave + (r & 3) + 8 * (r >> 2);
+        bias_r[r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nchunk = a.Cib / CB;
+    int xb = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int wb = ch & 1;
+        const bool more = ch + 1 < nchunk;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using NO = std::false_type;
+        using YES = std::true_type;
+        if constexpr (TPB == 1) {
+            iteration(I0{}, I0{}, YES{}, xb, wb, ch + 1, more); xb ^= 1;
+        } else if constexpr (TPB == 2) {
+            iteration(I0{}, I1{}, NO{}, xb, wb, ch, true); xb ^= 1;
+            iteration(I1{}, I0{}, YES{}, xb, wb, ch + 1, more); xb ^= 1;
+        } else {
+            iteration(I0{}, I1{}, NO{}, xb, wb, ch, true); xb ^= 1;
+            iteration(I1{}, I2{}, NO{}, xb, wb, ch, true); xb ^= 1;
+            iteration(I2{}, I3{}, NO{}, xb, wb, ch, true); xb ^= 1;
+            iteration(I3{}, I0{}, YES{}, xb, wb, ch + 1, more); xb ^= 1;
+        }
+    }
+
+    // ---- epilogue of every tile: bias (x 7/8 on the image's first / last row), scale, store, statistics entries
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rs_yb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long long)b * a.y_bs), 0, (unsigned)a.Co * HW4, 0x00020000);
+    const bool quads = a.ounit == 4;
+    const int ush = quads ? 2 : 3;
+    __amdgpu_buffer_rsrc_t rs_o = rs_yb;
+    if constexpr (EMIT_STATS)
+        rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ostats + (long long)b * (a.Co >> ush) * a.oslots), 0,
+                                                 (unsigned)(a.Co >> ush) * (unsigned)a.oslots * 16u, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < TPB; ++t) {
+        const int gh = h0 + t, gw = w0 + wpx * 32 + l31;
+        const bool pok = gh < H && gw < W;
+        const unsigned vo = pok ? (unsigned)(co_wave * HW + gh * W + gw) * 4u : OOB;
+        const float brow = (gh == 0 ? 0.875f : 1.0f) + (gh == H - 1 ? 0.875f : 1.0f) - 1.0f;
+        float st_p[4], st_s[4], st_q[4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cor = (r & 3) + 8 * (r >> 2);
+            const float v = (acc[t][r] * out_unscale + bias_r[r] * brow) * a.out_scale;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_yb, co_wave + cor < a.Co ? vo : OOB,
+                                                  (unsigned)cor * HW4, LC_DEF_AUX);
+            if constexpr (EMIT_STATS) {
+                const int m = r >> 2;
+                if ((r & 3) == 0) { st_p[m] = __builtin_amdgcn_readlane(pok ? v : 0.0f, 0); st_s[m] = 0.f; st_q[m] = 0.f; }
+                const float d = pok ? v - st_p[m] : 0.0f;
+                st_s[m] += d;
+                st_q[m] = fmaf(d, d, st_q[m]);
+            }
+        }
+        if constexpr (EMIT_STATS) {
+            const int nvalid = __popcll(__ballot(pok) & 0xFFFFFFFFull);
+            const int slot = (gh * a.tiles_w + tw_i) * 2 + wpx;
+            const bool mine = quads ? (lane & 31) >= 28 : lane >= 60;
+            const float nv = (float)((quads ? 4 : 8) * nvalid);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int co_oct = co0 + wco * 32 + 8 * m;
+                const float sh = half_sum_to_lane31_63(st_s[m]), qh = half_sum_to_lane31_63(st_q[m]);
+                const float sf = dpp_add<0x143, 0xC>(sh), qf = dpp_add<0x143, 0xC>(qh);
+                const int ent = quads ? (co_oct >> 2) + (lane >> 5) : (co_oct >> 3);
+                const unsigned eo = (mine && co_oct < a.Co && gh < H)
+                                        ? ((unsigned)ent * (unsigned)a.oslots + (unsigned)slot) * 16u + 4u * (lane & 3)
+                                        : OOB;
+                store_entry_4lanes(rs_o, st_p[m], nv, quads ? sh : sf, quads ? qh : qf, eo);
+            }
+        }
+    }
+}
+
 using S2Cfg = HCfg<2, 2, 1, 1, 1, 64, 3>;      // 4 waves, 64 co x (1 x 64) output pixels; LDS 129 KB: one block per CU
 
 }  // namespace
@@ -203,8 +437,22 @@ extern "C" int lc_conv2d_ring_s2_f16x2_ps_fwd(const void* x_split, const void* w
     a.tpb = tpb; a.vert = 1;
     dim3 grid(B * a.tiles_h * a.tiles_w / tpb, ncot);
     a.xcd = (grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
-    if (a.ostats) hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, true, true>), grid, dim3(C::NT), 0, lc_s(s), a);
-    else hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, false, true>), grid, dim3(C::NT), 0, lc_s(s), a);
+    // LC_S2_FORM=1: the first form (weights re-loaded per tile; conv_f16x2_ps_kernel<.., S2>) -- developer A/B, same bits
+    static const int form_env = [] { const char* e = getenv("LC_S2_FORM"); return e ? atoi(e) : 2; }();
+    if (form_env == 1) {
+        if (a.ostats) hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, true, true>), grid, dim3(C::NT), 0, lc_s(s), a);
+        else hipLaunchKernelGGL((conv_f16x2_ps_kernel<C, false, true>), grid, dim3(C::NT), 0, lc_s(s), a);
+        return lc_launch_status();
+    }
+#define LC_S2_LAUNCH(T)                                                                                          \
+    do {                                                                                                         \
+        if (a.ostats) hipLaunchKernelGGL((conv_s2_shared_w_kernel<T, true>), grid, dim3(256), 0, lc_s(s), a);    \
+        else hipLaunchKernelGGL((conv_s2_shared_w_kernel<T, false>), grid, dim3(256), 0, lc_s(s), a);            \
+    } while (0)
+    if (tpb == 4) LC_S2_LAUNCH(4);
+    else if (tpb == 2) LC_S2_LAUNCH(2);
+    else LC_S2_LAUNCH(1);
+#undef LC_S2_LAUNCH
     return lc_launch_status();
 }
 
