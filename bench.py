@@ -139,8 +139,8 @@ def measure_hbm_traffic(timeout_s: int = 150):
                 if row["Counter_Name"] != counter:
                     continue
                 k = row["Kernel_Name"]
-                # the 3x3 instantiations (HCfg<..., 3>) and the tall level-0 kernel (3x3 only)
-                if "conv_f16x2" in k and ("Li3EEEE" in k or ", 3>" in k or "tall_kernel" in k):
+                # the 3x3 instantiations (HCfg<..., 3>), the tall level-0 kernel and the stride-2 conv of the folded down path
+                if ("conv_f16x2" in k and ("Li3EEEE" in k or ", 3>" in k or "tall_kernel" in k)) or "conv_s2_shared_w" in k:
                     tot += float(row["Counter_Value"]) * 1024.0
                     n += 1
             if n == 0:
@@ -526,7 +526,7 @@ def main():
                     break
             tdetail = None
         roof = {"bound": "mfma",
-                "kernel": ("conv_f16x2_{tall,pipe,ps}_kernel<KS=3>" if split else "conv_ring_kernel<KS=3>") +
+                "kernel": ("conv_f16x2_{tall,pipe,ps}_kernel<KS=3> + conv_s2_shared_w_kernel" if split else "conv_ring_kernel<KS=3>") +
                           " (all tile instantiations)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,

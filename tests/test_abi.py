@@ -243,6 +243,17 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3   # steps/s of the job
+    if "r06" in os.path.basename(paths[-1]) or "rows" in d:
+        # round 6: per-rank verification, same-process rows behind their fixture checks, the box's calibration
+        v = d["verify"]
+        assert v["ok"] is True and v["ranks_verified"] == 1 and v["per_rank"][0]["samples"] == [0, 7]
+        for k in ("uncond_32x1024_batch1", "uncond_32x1024_batch32", "cond_layout_v6_32x1024_batch8"):
+            row = d["rows"][k]
+            assert row["ms_per_step"] > 0 and row["check"]["forward_max_rel_l2_vs_reference"] < row["check"]["tolerance"]
+        cal = d["box_calibration"]
+        assert cal["mfma_f16_tflops_random_operands"] > 100 and 1.0 < cal["stream_copy_tb_s"] < 8.0
+        assert abs(r["frac_of_box_ceiling"] - r["achieved"] / cal["three_product_ceiling_tflops"]) < 1e-3
+        assert r["achieved_executed"] <= r["achieved"]
 
 
 def test_single_product_library_loads():
