@@ -384,10 +384,9 @@ extern "C" int lc_fir_down2_prefilter_split(const float* x, int64_t x_bs, void* 
     if (!x || !y_split || !range || B <= 0 || C <= 0 || H <= 0 || W <= 0) return LC_EINVAL;
     if (C % 16 || H % 2 || H < 4 || W % 128) return LC_EUNSUP;      // 16-channel K chunks; whole 64-pixel output tiles
     if ((reinterpret_cast<uintptr_t>(x) & 7) || (x_bs & 1)) return LC_EUNSUP;   // float2 loads
-    // rows per strip: as long as possible (3 halo rows are re-read per strip) while the launch still has ~16 waves per CU
-    const long long per_row_strip = (long long)B * (C / 8) * ((W / 2 + 63) / 64);   // waves per strip index
+    // rows per strip: 8 (3 halo rows are re-read per strip).  Shorter strips for more waves were measured and lose on the
+    // small planes: 8 x 256 x 8 x 256: 20.6 us at 8 rows per strip, 21.1 at 2, 25.2 at 1 (profiles/r06_fold_down.txt section 2)
     int strip_len = 8;
-    while (strip_len > 1 && per_row_strip * ((H + strip_len) / strip_len) < 4096) strip_len >>= 1;
     static const int strip_env = [] { const char* e = getenv("LC_PF_STRIP"); return e ? atoi(e) : 0; }();
     if (strip_env > 0) strip_len = strip_env;
     const int nstrip = (H + 1 + strip_len - 1) / strip_len;
