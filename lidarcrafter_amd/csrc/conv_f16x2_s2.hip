@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void fir_down2_prefilter_split_kernel(
             const float in = (r >= 0 && r < H) ? 1.0f : 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                e[k] = in * (f0 * w.a[k] + f1 * w.m[k].x + f2 * w.m[k].y + f3 * w.c[k].x);          // column 2 i
-                o[k] = in * (f0 * w.m[k].x + f1 * w.m[k].y + f2 * w.c[k].x + f3 * w.c[k].y);        // column 2 i + 1
+                // (explicit fma chains: left to -ffp-contract the prologue and loop copies of this code were contracted
+                //  differently and the result depended on the strip length in its last bit)
+                e[k] = in * fmaf(f3, w.c[k].x, fmaf(f2, w.m[k].y, fmaf(f1, w.m[k].x, f0 * w.a[k])));        // column 2 i
+                o[k] = in * fmaf(f3, w.c[k].y, fmaf(f2, w.c[k].x, fmaf(f1, w.m[k].y, f0 * w.m[k].x)));      // column 2 i + 1
             }
         };
         auto put = [&](int row, const float (&e)[8], const float (&o)[8]) {
@@ -100,23 +102,23 @@ __global__ __launch_bounds__(256) void fir_down2_prefilter_split_kernel(
             float fe[8], fo[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                fe[k] = f0 * we[0][k] + f1 * we[1][k] + f2 * we[2][k] + f3 * we[3][k];
-                fo[k] = f0 * wo[0][k] + f1 * wo[1][k] + f2 * wo[2][k] + f3 * wo[3][k];
+                fe[k] = fmaf(f3, we[3][k], fmaf(f2, we[2][k], fmaf(f1, we[1][k], f0 * we[0][k])));
+                fo[k] = fmaf(f3, wo[3][k], fmaf(f2, wo[2][k], fmaf(f1, wo[1][k], f0 * wo[0][k])));
             }
             put(m + 1, fe, fo);
             if (m == 1) {                                               // top variant: F[1] without f0 * XW[0]
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    fe[k] = f1 * we[1][k] + f2 * we[2][k] + f3 * we[3][k];
-                    fo[k] = f1 * wo[1][k] + f2 * wo[2][k] + f3 * wo[3][k];
+                    fe[k] = fmaf(f3, we[3][k], fmaf(f2, we[2][k], f1 * we[1][k]));
+                    fo[k] = fmaf(f3, wo[3][k], fmaf(f2, wo[2][k], f1 * wo[1][k]));
                 }
                 put(H + 1, fe, fo);
             }
             if (m == H - 3) {                                           // bottom variant: F[H - 3] without f3 * XW[H - 1]
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    fe[k] = f0 * we[0][k] + f1 * we[1][k] + f2 * we[2][k];
-                    fo[k] = f0 * wo[0][k] + f1 * wo[1][k] + f2 * wo[2][k];
+                    fe[k] = fmaf(f2, we[2][k], fmaf(f1, we[1][k], f0 * we[0][k]));
+                    fo[k] = fmaf(f2, wo[2][k], fmaf(f1, wo[1][k], f0 * wo[0][k]));
                 }
                 put(H + 2, fe, fo);
             }
