@@ -82,6 +82,32 @@ def test_no_cpu_fallback():
     m = EfficientUNet(2, (8, 64), base_channels=16, coords_encoding="fourier_features")
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 2, 8, 64), torch.zeros(1))
+    # the folded down-sampling stage (round 6): eligibility is a pure predicate, the op itself refuses CPU tensors
+    assert ops.can_fold_down(64, 128, 32, 1024) and ops.can_fold_down(16, 32, 4, 128)
+    assert not ops.can_fold_down(64, 128, 32, 1000) and not ops.can_fold_down(24, 48, 32, 1024)   # W % 128, Ci % 16
+    assert not ops.can_fold_down(64, 128, 3, 1024) and not ops.can_fold_down(64, 128, 2, 1024)     # H odd / H < 4
+    pk = ops.PackedConv("down")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv_down2(torch.zeros(1, 16, 4, 128), pk, torch.zeros(32, 16, 3, 3), None)
+
+
+def test_fold_down_symbols_reject_bad_shapes():
+    """The C entry points of the folded stage validate their arguments before any launch (no GPU needed)."""
+    from lidarcrafter_amd import _lib
+
+    LC_EINVAL, LC_EUNSUP = -1, -2
+    h = _lib.lib()
+    assert h.lc_fir_down2_split_units(8, 64, 32, 1024) == 8 * 2 * 8 * 35 * 1024
+    assert h.lc_fir_down2_split_units(8, 60, 32, 1024) == 0                       # C % 8
+    assert h.lc_conv2d_ring_s2_stats_slots(16, 512) == 16 * 8 * 2 and h.lc_conv2d_ring_s2_stats_slots(16, 500) == 0
+    p = 4096
+    assert h.lc_fir_down2_prefilter_split(None, 0, p, 1, 16, 4, 128, p, None) == LC_EINVAL
+    assert h.lc_fir_down2_prefilter_split(p, 16 * 4 * 128, p, 1, 24, 4, 128, p, None) == LC_EUNSUP     # C % 16
+    assert h.lc_fir_down2_prefilter_split(p, 16 * 3 * 128, p, 1, 16, 3, 128, p, None) == LC_EUNSUP     # H odd
+    assert h.lc_fir_down2_prefilter_split(p, 16 * 4 * 64, p, 1, 16, 4, 64, p, None) == LC_EUNSUP       # W % 128
+    assert h.lc_conv2d_ring_s2_f16x2_ps_fwd(p, p, p, None, None, 0, 1, 16, 32, 2, 64, 1.0, None, 8, p, p, None) == LC_EINVAL
+    assert h.lc_conv2d_ring_s2_f16x2_ps_fwd(p, p, p, None, p, 0, 1, 24, 32, 2, 64, 1.0, None, 8, p, p, None) == LC_EUNSUP
+    assert h.lc_conv2d_ring_s2_f16x2_ps_fwd(p, p, p, None, p, 0, 1, 16, 32, 2, 48, 1.0, None, 8, p, p, None) == LC_EUNSUP
 
 
 def test_product_never_imports_oracle():
