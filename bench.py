@@ -335,6 +335,20 @@ def extra_rows(device, steps_small: int = 20):
             "algorithmic_tflops": round(B * GFLOP_PER_SAMPLE_STEP / dt / 1e3, 1),
             "check": {"forward_max_rel_l2_vs_reference": float(f"{r:.3g}"), "tolerance": 2e-5,
                       "against": "tests/golden/c2_b8.npz y_s4 (samples of a batch are independent in the reference)"}}
+    # whole `sample()` calls, as tools/generate and the bulk harness issue them (one per batch): the first call of a shape
+    # runs its first step eagerly and captures the step's HIP graph, later calls replay that graph from step 0
+    calls = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        xs = ddpm.sample(8, 50, progress=False, rng=None, mode="ddim")
+        torch.cuda.synchronize()
+        calls.append(round((time.perf_counter() - t0) * 1e3, 2))
+    assert torch.isfinite(xs).all()
+    rows["uncond_32x1024_batch8_sample_call"] = {
+        "ddim_steps": 50, "ms_per_call": calls,
+        "note": "wall time of ddpm.sample(8, 50, mode='ddim') calls on one sampler, in order; 50 x the headline's "
+                "ms_per_step is the floor; the range poll at the end of a call is one blocking 64 KB copy"}
     del ddpm
     g = np.load(os.path.join(ROOT, "tests", "golden", "c3_b8.npz"))
     cfg = CONFIGS["nuscenes-box-layout-v6"]()

@@ -25,18 +25,21 @@ def main():
         ddpm = ddpm.eval().to(dev)
         cond = "layout" in name
         batch = {k: v.to(dev) for k, v in synth_layout_batch(B, 32, 1024, seed=83).items()} if cond else None
-        ts, outs = [], []
-        for call in range(4):
-            rng = [torch.Generator().manual_seed(i) for i in range(B)]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            x = ddpm.sample(batch, B, S, progress=False, rng=rng, mode="ddim") if cond else \
-                ddpm.sample(B, S, progress=False, rng=rng, mode="ddim")
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) * 1e3)
-            outs.append(x.clone())
-        same = all(torch.equal(outs[0], o) for o in outs[1:])
-        print(f"{name} B={B} {S} DDIM steps: sample() calls {', '.join(f'{t:.1f}' for t in ts)} ms; repeat calls bit-equal: {same}", flush=True)
+        for cache in (0, 4):                     # 0: every call pays an eager first step + a capture (rounds 1-5)
+            ddpm.graph_cache_size = cache
+            ts, outs = [], []
+            for call in range(4):
+                rng = [torch.Generator().manual_seed(i) for i in range(B)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                x = ddpm.sample(batch, B, S, progress=False, rng=rng, mode="ddim") if cond else \
+                    ddpm.sample(B, S, progress=False, rng=rng, mode="ddim")
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+                outs.append(x.clone())
+            same = all(torch.equal(outs[0], o) for o in outs[1:])
+            print(f"{name} B={B} {S} DDIM steps, graph cache {cache}: sample() calls {', '.join(f'{t:.1f}' for t in ts)} ms; "
+                  f"repeat calls bit-equal: {same}", flush=True)
 
 
 if __name__ == "__main__":

@@ -3,10 +3,16 @@
 from __future__ import annotations
 
 import contextlib
+import weakref
 from typing import List, Literal
 
 import torch
 from torch import nn
+
+
+# sampler -> pinned staging buffers + their events: kept outside the module's __dict__ (events neither copy nor pickle:
+# copy.deepcopy(ddpm) -- the reference trainers' EMA wrapper -- after a seeded sampling run would fail on them)
+_RNG_STAGES = weakref.WeakKeyDictionary()
 
 
 class GaussianDiffusion(nn.Module):
@@ -78,7 +84,7 @@ class GaussianDiffusion(nn.Module):
         in the same order as per-sample `randn(...).to(device)` -- and ONE asynchronous copy moves
         the batch (DDPM draws noise every step: eight blocking 256 KB copies + a device stack cost
         1.4 ms per step at batch 8).  Two staging buffers alternate; an event guards reuse."""
-        ring = self.__dict__.setdefault("_rng_stage", {})
+        ring = _RNG_STAGES.setdefault(self, {})
         key = (tuple(shape), dtype)
         ent = ring.get(key)
         if ent is None:

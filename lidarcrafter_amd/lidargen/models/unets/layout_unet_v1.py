@@ -158,8 +158,9 @@ class ObjectAwareCrossAttention(nn.Module):
         self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
         self._cond_cache = None
 
-    def condition_operands(self, cond):
-        """Step-invariant operands (reference recomputes them every step, :431-476)."""
+    def condition_operands(self, cond, refresh=False):
+        """Step-invariant operands (reference recomputes them every step, :431-476).  `refresh`: recompute even when the
+        cache key matches (a new condition may live at the addresses of the previous one)."""
         img = cond[f"image_patch_bbox_embedding_for_resolution{self.resolution}"]
         mask = cond["key_padding_mask"] if self.use_key_padding_mask else None
         key = (img.data_ptr(), cond["obj_bbox_embedding"].data_ptr(), cond["xf_out"].data_ptr(),
@@ -167,7 +168,7 @@ class ObjectAwareCrossAttention(nn.Module):
                self.layout_position_embedding_projector.weight._version,
                self.layout_content_embedding_projector.weight._version,
                None if mask is None else (mask.data_ptr(), _ver(mask)))
-        if self._cond_cache is None or self._cond_cache[0] != key:
+        if refresh or self._cond_cache is None or self._cond_cache[0] != key:
             C = self.channels
             proj = self.layout_position_embedding_projector
             if self.norm_first:                                     # :431-433, :457-459
@@ -195,8 +196,25 @@ class ObjectAwareCrossAttention(nn.Module):
             # the keyed tensors are kept alive by the cache: their addresses cannot be handed to
             # a different condition while it is valid (versions are not tracked in inference mode)
             hold = (img, cond["obj_bbox_embedding"], cond["xf_out"], cond["obj_class_embedding"], mask)
-            self._cond_cache = (key, pos_img, pos_lay, k_lay, v_lay, per_sample, hold)
+            ops4 = self._refill(self._cond_cache, (pos_img, pos_lay, k_lay, v_lay), per_sample)
+            self._cond_cache = (key,) + ops4 + (per_sample, hold)
         return self._cond_cache[1:6]
+
+    def _refill(self, old, new4, per_sample):
+        """The operands of a NEW condition go into the tensors of the previous one when they fit (same shapes, inside a
+        sampling run): their addresses then stay what a captured denoising step reads, and the sampler can replay the
+        graph of an earlier run (continuous_time.py::_graph_key) instead of capturing one per condition.  Never when
+        the layer hands its operands out (`return_attention_embeddings`) or carries per-sample key sets."""
+        if old is None or per_sample is not None or old[5] is not None or self.return_attention_embeddings \
+                or not torch.is_inference_mode_enabled():
+            return tuple(new4)
+        prev = old[1:5]
+        if not all(o.is_inference() and o.shape == n.shape and o.dtype == n.dtype and o.device == n.device
+                   for o, n in zip(prev, new4)):
+            return tuple(new4)
+        for o, n in zip(prev, new4):
+            o.copy_(n)
+        return tuple(prev)
 
     def forward(self, x, cond_kwargs, out=None):
         B, C, H, W = x.shape
@@ -405,14 +423,36 @@ class LayoutUnetV1(nn.Module):
 
     def prepare_condition(self, layout_outputs: dict):
         """Compute everything that depends only on the layout condition (once per batch)."""
-        if self._in_buf is not None:          # a new condition: recopy its channels next forward
-            self._in_buf = (self._in_buf[0], self._in_buf[1], None)
+        if self._in_buf is not None:          # a new condition: recopy its channels (now when the buffer of this
+            self._in_buf = (self._in_buf[0], self._in_buf[1], None)   # batch exists, else in the next forward)
+            cc = layout_outputs.get("concat_cond")
+            buf = self._in_buf[1]
+            if cc is not None and buf.shape[0] == cc.shape[0] and buf.device == cc.device:
+                self._bind_concat(buf, cc, self.in_channels - cc.shape[1])
+        for m in self._attention_layers():
+            m.condition_operands(layout_outputs, refresh=True)   # never trust a cache across conditions
+
+    def _attention_layers(self):
         seqs = list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
-        for s in seqs:
-            for m in s:
-                if isinstance(m, ObjectAwareCrossAttention):
-                    m._cond_cache = None      # never trust a cache across conditions
-                    m.condition_operands(layout_outputs)
+        return [m for s in seqs for m in s if isinstance(m, ObjectAwareCrossAttention)]
+
+    def graph_operands(self):
+        """The condition tensors a captured denoising step reads by address (every attention layer's step-invariant
+        operands), or None when a step cannot be replayed across conditions (per-sample key sets, nothing prepared)."""
+        out = []
+        for m in self._attention_layers():
+            c = m._cond_cache
+            if c is None or c[5] is not None:
+                return None
+            out.extend(c[1:5])
+        return out
+
+    def _bind_concat(self, buf, cc, cx):
+        """Condition channels are step-invariant: copied into the resident input buffer once per condition."""
+        ck = (cc.data_ptr(), _ver(cc), cc)       # holds cc: its address cannot be reused meanwhile
+        if self._in_buf[2] is None or self._in_buf[2][:2] != ck[:2]:
+            K.copy_into(buf[:, cx:cx + cc.shape[1]], cc.float().contiguous())
+            self._in_buf = (self._in_buf[0], buf, ck)
 
     @torch.compiler.disable
     @K.range_checked
@@ -433,12 +473,7 @@ class LayoutUnetV1(nn.Module):
         if x.data_ptr() != buf.data_ptr():
             K.copy_into(buf[:, :cx], x)
         if "concat_cond" in lay:
-            cc = lay["concat_cond"]
-            ck = (cc.data_ptr(), _ver(cc), cc)   # holds cc: its address cannot be reused meanwhile
-            if self._in_buf[2] is None or self._in_buf[2][:2] != ck[:2]:
-                # condition channels are step-invariant: copy once per condition
-                K.copy_into(buf[:, cx:cx + cc.shape[1]], cc.float().contiguous())
-                self._in_buf = (self._in_buf[0], buf, ck)
+            self._bind_concat(buf, lay["concat_cond"], cx)
         dev = x.device
         # pre-concatenated buffers: output block j reads cat[h, skip_(n-1-j)]
         n_in = len(self.input_blocks)

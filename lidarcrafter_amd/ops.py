@@ -187,6 +187,26 @@ def set_conv_precision(mode: str) -> str:
     return old
 
 
+# What a captured denoising step depends on besides its tensors: every routing switch of this module (the upper-case
+# scalars: precision, fusion thresholds, statistics routes, fold / split-K switches ...), the effective product count
+# (autocast included) and an epoch that moves whenever a packed weight is rebuilt, a range slot is (re)assigned or a
+# pre-scale is moved by the poll.  A sampler may replay a graph captured by an EARLIER run only under an equal signature
+# (lidargen/models/diffusion/continuous_time.py::_graph_key).
+_EPOCH = 0
+
+
+def bump_epoch() -> None:
+    global _EPOCH
+    _EPOCH += 1
+
+
+def route_signature() -> tuple:
+    g = globals()
+    flags = tuple((k, g[k]) for k in sorted(g) if k.isupper() and k != "_EPOCH"
+                  and isinstance(g[k], (bool, int, float, str, tuple, type(None))))
+    return flags + (conv_products(), _EPOCH)
+
+
 # ------------------------------------------------------------------------------------ GN stats
 # Producer-side GroupNorm statistics: the pipelined f16x2 conv can emit, per octet of output
 # channels and wave tile, the shifted sums of what it stores (lc_conv2d_ring_f16x2_fwd
@@ -404,6 +424,7 @@ class _RangeArena:
         if not self.free:
             raise RuntimeError("range arena exhausted (more than 4096 live conv layers)")
         slot = self.free.pop()
+        bump_epoch()
         self.owner[slot] = weakref.ref(owner)
         self.device_managed.discard(slot)
         # a recycled slot starts clean: a running maximum left by its previous owner would hide
@@ -418,6 +439,7 @@ class _RangeArena:
         self.free.append(slot)                   # (re-initialised by the next alloc)
 
     def _set_scale(self, slot: int, scale: float) -> None:
+        bump_epoch()
         self.scale[slot] = scale
         self.buf[slot, :2] = torch.tensor([scale, 1.0 / scale], dtype=_F32)
 
@@ -715,6 +737,7 @@ class PackedConv:
             self.Co, self.Ci, self.ks, self._key = Co, Ci, kh, key
             self._w4 = w.contiguous()
             self.wp = self.wh = self.wl = None
+            bump_epoch()
 
     def get(self, weight: torch.Tensor) -> torch.Tensor:
         self._refresh(weight)
@@ -1980,7 +2003,8 @@ def _wrap_public_ops():
 
     g = globals()
     skip = {"fuse_gn", "set_conv_precision", "range_poll", "range_checked", "defer_range_checks",
-            "name_packed_convs", "rng_snapshot", "rng_restore", "run_range_safe", "can_presplit"}
+            "name_packed_convs", "rng_snapshot", "rng_restore", "run_range_safe", "can_presplit", "bump_epoch",
+            "route_signature"}
     for name, obj in list(g.items()):
         if isinstance(obj, types.FunctionType) and not name.startswith("_") and name not in skip \
                 and obj.__module__ == __name__ and not getattr(obj, "_lc_entry", False):

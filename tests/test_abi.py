@@ -291,3 +291,29 @@ def test_single_product_library_loads():
     for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd"):
         assert getattr(h, name).argtypes == _lib.SIGNATURES[name][1]
     assert ops.conv_products() == 3            # never the default
+
+
+def test_route_signature_moves_with_switches_and_epoch(monkeypatch):
+    """ops.route_signature() is part of the key under which a sampler replays a graph captured by an earlier run
+    (continuous_time.py::_graph_key): every routing switch of ops, the effective product count and the epoch of the
+    packed weights / range slots must move it."""
+    from lidarcrafter_amd import ops as K
+
+    base = K.route_signature()
+    assert K.route_signature() == base
+    for name in ("PRODUCER_GN_STATS", "RESAMPLE_STATS", "FUSE_GN", "PRESPLIT", "FOLD_DOWN", "SPLITK"):
+        monkeypatch.setattr(K, name, not getattr(K, name))
+        assert K.route_signature() != base, name
+        monkeypatch.undo()
+    for name, val in (("CONV_PRECISION", "f32"), ("ATTN_PRECISION", "f32"), ("FUSE_GN_MAX_CO", 128), ("PS1X1_MIN_CO", 0)):
+        monkeypatch.setattr(K, name, val)
+        assert K.route_signature() != base, name
+        monkeypatch.undo()
+    old = K.set_conv_products(1)
+    try:
+        assert K.route_signature() != base
+    finally:
+        K.set_conv_products(old)
+    assert K.route_signature() == base
+    K.bump_epoch()
+    assert K.route_signature() != base
