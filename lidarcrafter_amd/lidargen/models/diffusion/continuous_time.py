@@ -229,15 +229,24 @@ class ContinuousTimeGaussianDiffusion(base.GaussianDiffusion):
     graph_cache_size = 4
 
     def _weights_fingerprint(self):
-        mods = [self.model] + ([self.condition_model] if isinstance(self.condition_model, nn.Module) else [])
-        fp = []
-        for m in mods:
-            for t in list(m.parameters()) + list(m.buffers()):
-                try:
-                    v = t._version
-                except RuntimeError:                # inference tensors carry no version counter
-                    v = -1
-                fp.append((t.data_ptr(), v))
+        """(address, version) of every parameter and buffer below the denoiser and the condition model.  A plain walk over
+        `_modules` (nn.Module.parameters() builds a dotted name per tensor: 2.8 ms for the layout model, once per run)."""
+        fp, seen = [], set()
+        stack = [self.model] + ([self.condition_model] if isinstance(self.condition_model, nn.Module) else [])
+        while stack:
+            m = stack.pop()
+            if id(m) in seen:
+                continue
+            seen.add(id(m))
+            for d in (m._parameters, m._buffers):
+                for t in d.values():
+                    if t is not None:
+                        try:
+                            v = t._version
+                        except RuntimeError:        # inference tensors carry no version counter
+                            v = -1
+                        fp.append((t.data_ptr(), v))
+            stack.extend(c for c in m._modules.values() if c is not None)
         return tuple(fp)
 
     def _graph_key(self, st):

@@ -121,6 +121,22 @@ class LayoutTransformerEncoder(nn.Module):
                 [(dj * j, di * i, dj * (j + 1), di * (i + 1)) for i in range(nh) for j in range(nw)])
         self.out_channels = kwargs.get("out_channels", 10)
 
+    def _patch_embedding(self, key, dev):
+        """Embedding of the feature-map cells of one attention level: a function of `obj_bbox_2d_embedding` alone (the
+        reference recomputes it per forward, layout_encoder.py:228-237).  Kept per (weights, device) outside grad mode."""
+        lin = self.obj_bbox_2d_embedding
+        if torch.is_grad_enabled() and (lin.weight.requires_grad or lin.bias.requires_grad):
+            cells = self.image_patch_bbox_embedding[key].to(dev, self.dtype)
+            return lin(cells).t().contiguous(), None
+        tag = (key, str(dev), lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version)
+        cache = self.__dict__.setdefault("_patch_cache", {})
+        ent = cache.get(key)
+        if ent is None or ent[0] != tag:
+            cells = self.image_patch_bbox_embedding[key].to(dev, self.dtype)
+            with torch.no_grad():
+                ent = cache[key] = (tag, lin(cells).t().contiguous())
+        return ent[1], tag
+
     def forward(self, condition_dict, obj_class=None, obj_bbox=None, obj_mask=None,
                 is_valid_obj=None, image_patch_bbox=None):
         boxes = condition_dict["scaled_gt_boxes"]
@@ -142,10 +158,14 @@ class LayoutTransformerEncoder(nn.Module):
             out["obj_bbox_embedding"] = e2.permute(0, 2, 1).contiguous()
             for r in self.resolution_to_attention:
                 key = f"resolution{int(self.feature_map_size[0] / r)}"
-                cells = self.image_patch_bbox_embedding[key].to(dev, self.dtype)
-                emb = self.obj_bbox_2d_embedding(cells).t().contiguous()          # [hidden, L]
+                emb, tag = self._patch_embedding(key, dev)                        # [hidden, L]
                 # same rows for every sample: a stride-0 batch view, not B copies
-                out["image_patch_bbox_embedding_for_" + key] = emb[None].expand(e3.shape[0], -1, -1)
+                view = emb[None].expand(e3.shape[0], -1, -1)
+                # (the rows depend on this module's weights only, not on the condition: a consumer that has
+                #  derived something from a view with the same tag need not derive it again --
+                #  ObjectAwareCrossAttention.condition_operands)
+                view._lc_weights_only = tag
+                out["image_patch_bbox_embedding_for_" + key] = view
         if "obj_mask" in self.used_condition_types:
             m = self.obj_mask_embedding(obj_mask.view(*obj_mask.shape[:2], -1).to(self.dtype))
             xf_in = m if xf_in is None else xf_in + m

@@ -171,11 +171,24 @@ class ObjectAwareCrossAttention(nn.Module):
         if refresh or self._cond_cache is None or self._cond_cache[0] != key:
             C = self.channels
             proj = self.layout_position_embedding_projector
-            if self.norm_first:                                     # :431-433, :457-459
-                pos_img = proj(self.norm_for_image_patch_positional_embedding(img))
+            nimg = self.norm_for_image_patch_positional_embedding
+            # the image-side positional operand is a function of weights only when the encoder says so (its tag) and this
+            # layer's own weights have not moved: kept across conditions
+            itag = getattr(img, "_lc_weights_only", None)
+            if itag is not None:
+                itag = (itag, tuple(img.shape), proj.weight.data_ptr(), _ver(proj.weight), _ver(proj.bias),
+                        _ver(nimg.weight), _ver(nimg.bias))
+            old = self._cond_cache
+            if itag is not None and old is not None and len(old) > 7 and old[7] == itag and old[1].is_inference() \
+                    and torch.is_inference_mode_enabled():
+                pos_img = old[1]
+            elif self.norm_first:                                   # :431-433
+                pos_img = proj(nimg(img))
+            else:                                                   # :435-438
+                pos_img = nimg(proj(img))
+            if self.norm_first:                                     # :457-459
                 pos_lay = proj(self.norm_for_layout_positional_embedding(cond["obj_bbox_embedding"]))
-            else:                                                   # :435-438, :461-462
-                pos_img = self.norm_for_image_patch_positional_embedding(proj(img))
+            else:                                                   # :461-462
                 pos_lay = self.norm_for_layout_positional_embedding(proj(cond["obj_bbox_embedding"]))
             cls = self.norm_for_obj_class_embedding(cond["obj_class_embedding"])
             B, E, L2 = cls.shape
@@ -197,7 +210,7 @@ class ObjectAwareCrossAttention(nn.Module):
             # a different condition while it is valid (versions are not tracked in inference mode)
             hold = (img, cond["obj_bbox_embedding"], cond["xf_out"], cond["obj_class_embedding"], mask)
             ops4 = self._refill(self._cond_cache, (pos_img, pos_lay, k_lay, v_lay), per_sample)
-            self._cond_cache = (key,) + ops4 + (per_sample, hold)
+            self._cond_cache = (key,) + ops4 + (per_sample, hold, itag)
         return self._cond_cache[1:6]
 
     def _refill(self, old, new4, per_sample):
@@ -213,7 +226,8 @@ class ObjectAwareCrossAttention(nn.Module):
                    for o, n in zip(prev, new4)):
             return tuple(new4)
         for o, n in zip(prev, new4):
-            o.copy_(n)
+            if o is not n:                       # (the image-side operand may BE the previous one: weights only)
+                o.copy_(n)
         return tuple(prev)
 
     def forward(self, x, cond_kwargs, out=None):

@@ -112,6 +112,18 @@ def test_layout_conditions_share_one_capture(dev, monkeypatch):
     assert torch.equal(run(57, 0), ref[57, 0]) and cap.n == 1   # new condition, old graph
     assert torch.equal(run(57, 4), ref[57, 4]) and cap.n == 1
     assert torch.equal(run(51, 0), ref[51, 0]) and cap.n == 1
+    # the image-side positional operand is kept across conditions while the weights behind it stand still
+    # (layout_encoder._patch_embedding's tag): move one of them -- operand and graph key must follow
+    with torch.no_grad():
+        ddpm.condition_model.obj_bbox_2d_embedding.weight.mul_(1.25)
+    moved = run(57, 4)
+    assert cap.n == 2 and not torch.equal(moved, ref[57, 4])
+    m2, enc2 = build_cond_pair((8, 64), 8, 32)
+    fresh = CondContinuousTimeGaussianDiffusion(m2, enc2, cond_mode="concat").eval().to(dev)
+    fresh.graph_cache_size = 0
+    with torch.no_grad():
+        fresh.condition_model.obj_bbox_2d_embedding.weight.mul_(1.25)
+    assert torch.equal(moved, fresh.sample(dict(batches[57]), 2, 5, progress=False, rng=_gens(2, 4), mode="ddim"))
 
 
 def test_masked_layout_keys_are_never_shared(dev, monkeypatch):
