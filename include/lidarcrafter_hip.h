@@ -347,6 +347,29 @@ int lc_attention_f16x2_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos,
                            int64_t o_bs, int64_t o_hs, int64_t o_cs, int B, int heads, int Lq,
                            int Lk0, int Lk1, int dqk, int dpos, int dv, float scale,
                            lc_stream_t s);
+/* Keys and values in UNIT FORM (round 6; csrc/attention_units.hip): the fp16 hi / lo split of lc_attention_f16x2_fwd
+ * made once per step (or once per condition, for the step-invariant positional channels and the layout keys of
+ * ObjectAwareCrossAttention, layout_unet_v1.py:431-476) instead of once per query block inside the attention kernel.
+ * kv: [B][heads][tiles = Lk0 / 32 + (Lk1 > 0)][768] units of 8 halves -- per 32-key tile K hi, K lo ([8 channels-octets][32
+ * keys]) and V hi, V lo ([2][2][32 channels], keys in MFMA accumulator order); zero where a head has no channel / key.
+ * lc_attention_units_elems: halves to allocate (zero-filled by the caller), -1 for unsupported sizes (Lk0 % 32, Lk1 > 32).
+ * lc_attention_pack_units: which = 0 writes keys (src: [B][heads * d][L] fp32 channel-major; the d channels land in
+ * octets cb0 ... of a head's 64 q/k channels), which = 1 values (d <= 32); key0 (multiple of 32) = first destination key.
+ * lc_attention_units_fwd: same result, bit for bit, as lc_attention_f16x2_fwd on the operands the units were packed
+ * from (dqk + dpos <= 64, both multiples of 8, dv <= 32). */
+/* lc_conv1x1_f16x2_ps_qkv_fwd: the qkv projection of ObjectAwareCrossAttention (conv_nd(1, C, 3 C, 1),
+ * layout_unet_v1.py:381,416-430) on a pre-split input (lc_groupnorm_apply*_split) whose key and value rows are written
+ * in unit form by the kernel's own epilogue -- q [B][C][H * W] fp32 (batch stride q_bs); 32 channels per head,
+ * C % 128 == 0, (H * W) % 32 == 0; kv sized by lc_attention_units_elems(B, C / 32, H * W, Lk1). */
+int lc_conv1x1_f16x2_ps_qkv_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias, float* q,
+                                int64_t q_bs, void* kv, int B, int Ci, int C, int H, int W, int Lk1, const float* wmeta,
+                                lc_conv_range* range, lc_stream_t s);
+int64_t lc_attention_units_elems(int B, int heads, int Lk0, int Lk1);
+int lc_attention_pack_units(const lc_cm_operand* src, void* kv, int B, int heads, int L, int Lk0, int Lk1, int d,
+                            int cb0, int key0, int which, lc_stream_t s);
+int lc_attention_units_fwd(const lc_cm_operand* q, const lc_cm_operand* q_pos, const void* kv, float* o,
+                           int64_t o_bs, int64_t o_hs, int64_t o_cs, int B, int heads, int Lq, int Lk0, int Lk1,
+                           int dqk, int dpos, int dv, float scale, lc_stream_t s);
 /* ---------------------------------------------------------------------------------------------
  * Training: the same attention with a backward pass, so that loss.backward() never materialises
  * the [B*heads, Lq, Lk] scores or their gradient (autograd of nn.MultiheadAttention efficient_unet.py:28-58 and

@@ -97,6 +97,10 @@ SIGNATURES = {
                                i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "lc_attention_f16x2_fwd": (i32, [_op, _op, _op, _op, _op, _op, _op, _op, vp, i64, i64, i64,
                                      i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "lc_conv1x1_f16x2_ps_qkv_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "lc_attention_units_elems": (i64, [i32, i32, i32, i32]),
+    "lc_attention_pack_units": (i32, [_op, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "lc_attention_units_fwd": (i32, [_op, _op, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "lc_attention_train_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp, vp]),
     "lc_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
     "lc_attention_bwd_f16x2": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]),
@@ -140,7 +144,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3   # include/lidarcrafter_hip.h lc_abi_version: bumped with every change of an exported signature
+ABI_VERSION = 4   # include/lidarcrafter_hip.h lc_abi_version: bumped with every change of an exported signature
 
 
 class HipLibraryMissing(RuntimeError):
@@ -177,7 +181,8 @@ def lib_p1() -> C.CDLL:
         if not os.path.exists(path):
             raise HipLibraryMissing(f"{path} not found: run `python -m lidarcrafter_amd.build`")
         handle = C.CDLL(path)
-        for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd", "lc_conv1x1_f16x2_ps_fwd"):
+        for name in ("lc_conv2d_ring_f16x2_fwd", "lc_conv2d_ring_f16x2_ps_fwd", "lc_conv1x1_f16x2_ps_fwd",
+                     "lc_conv1x1_f16x2_ps_qkv_fwd"):
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = SIGNATURES[name]
         _lib_p1 = handle

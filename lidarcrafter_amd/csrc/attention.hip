@@ -175,31 +175,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 //        A = V unit [step][half][c] holding V[c][kappa(8*step + 0..7, half)] -- the staging
 //        pass writes each thread's 8 consecutive keys as two 8-byte pieces into that order.
 // K/V of the next tile are prefetched into registers while the current tile is computed.
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
+#include "attention_split.h"
 #include "attention_pre.h"
-
-constexpr float QK_PRE = 16.0f;      // q (after the softmax scale) and k are pre-scaled by 16
-constexpr float P_PRE = 2048.0f;     // p in [0,1]
-constexpr float P_LOG2 = 11.0f;      // log2(P_PRE)
-constexpr float V_PRE = 16.0f;
-
-__device__ __forceinline__ void split8(const float (&v)[8], float scale, half8& hi, half8& lo) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-        const float s0 = scale == 1.0f ? v[k] : v[k] * scale;
-        const float s1 = scale == 1.0f ? v[k + 1] : v[k + 1] * scale;
-        const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
-        const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
-        const h2 ph = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-        f2 r; r.x = s0 - h0; r.y = s1 - h1;
-        const h2 pl = __builtin_convertvector(r, h2);
-        hi[k] = ph.x; hi[k + 1] = ph.y; lo[k] = pl.x; lo[k + 1] = pl.y;
-    }
-}
 
 // NW = waves per block (32 queries each).  4: the block of rounds 1-4.  8 (round 5): the K / V staging of a tile is
 // per-BLOCK work (~75 of the ~250 VALU instructions a wave spends per 32-key tile, profiles/r04_pmc_attn.txt); 256

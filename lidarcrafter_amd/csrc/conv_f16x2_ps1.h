@@ -34,8 +34,26 @@ struct P1Args {
     float* y; long long y_bs;
     int Co; float out_scale;
     const lc_conv_range* range; const float* wmeta;
+    // QKV form (conv1x1_ps_kernel<true>): Co = 3 C; rows [0, C) are written to y as fp32, rows [C, 2C) and [2C, 3C) --
+    // the keys and values of ObjectAwareCrossAttention, 32 channels per head -- go straight into the unit form the
+    // attention kernel stages by LDS-DMA (csrc/attention_units.hip; kv: [B][heads][kv_tiles][768] units of 8 halves)
+    half8* kv; int C, kv_heads, kv_tiles;
 };
 
+// The 8-byte halves of a K unit / the 16-byte V units a lane of the QKV epilogue owns; the split is the attention kernels'
+// own (attention_split.h: pre-scale 16, hi = 11 leading bits, lo = fp16(rest)).
+__device__ __forceinline__ void qkv_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float s0 = a * 16.0f, s1 = b * 16.0f;
+    const float h0 = __uint_as_float(__float_as_uint(s0) & 0xFFFFE000u);
+    const float h1 = __uint_as_float(__float_as_uint(s1) & 0xFFFFE000u);
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+    f2 r; r.x = s0 - h0; r.y = s1 - h1;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+}
+
+template <bool QKV>
 __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
     constexpr int BN = P1::BN, BP = P1::BP, CBK = P1::CBK, XS = P1::XS, WS = P1::WS, BUF = P1::BUF;
     constexpr int NX = P1::NX, NW = P1::NW, IPW = P1::IPW;
@@ -95,6 +113,9 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
     const int nchunk = a.C8 / CBK;
     half8* cur = lds;
     half8* nxt = lds + BUF;
+    // QKV: the blocks of the value rows run the MFMAs with the operands exchanged -- the accumulator of a lane is then
+    // one CHANNEL x 16 pixels in the order the attention kernel contracts keys in, i.e. two whole V units
+    const bool vt = QKV && co0 >= 2 * a.C;                   // (block-uniform)
     issue(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -117,14 +138,25 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
                 bh[j] = xh[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
                 bl[j] = xl[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
             }
+            if (QKV && vt) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < 2; ++j) {
+                        if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -135,6 +167,57 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
     const float out_unscale = a.range->x_unscale * a.wmeta[1];
     float* yb = a.y + (long long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    if (QKV && co0 >= a.C) {
+        // ---- keys / values -> unit form.  Tile image (768 units): K hi [cb 8][key 32] | K lo | V hi [step 2][half 2][c 32] | V lo
+        const float us = out_unscale, os = a.out_scale;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cpart = (vt ? co0 - 2 * a.C : co0 - a.C) + wco * 64 + i * 32;      // first channel of this 32-block
+            const int head = cpart >> 5;                                                  // = one head's 32 channels
+            half8* hb = a.kv + ((long long)(b * a.kv_heads + head) * a.kv_tiles) * 768;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pg = p0 + wpx * 64 + j * 32;                                    // 32 pixels = one key tile
+                if (pg >= a.P) continue;
+                half8* tile = hb + (long long)(pg >> 5) * 768;
+                if (!vt) {
+                    // lane = key l31, registers = channels (r & 3) + 8 (r >> 2) + 4 kh: the kh-th 8-byte half of units cb = r >> 2
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        float v[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const int co = co0 + wco * 64 + i * 32 + 8 * cb + 4 * kh + m;
+                            v[m] = (acc[i][j][4 * cb + m] * us + (a.bias ? a.bias[co] : 0.0f)) * os;
+                        }
+                        uint2 hi, lo;
+                        qkv_split2(v[0], v[1], hi.x, lo.x);
+                        qkv_split2(v[2], v[3], hi.y, lo.y);
+                        *(reinterpret_cast<uint2*>(&tile[cb * 32 + l31]) + kh) = hi;
+                        *(reinterpret_cast<uint2*>(&tile[256 + cb * 32 + l31]) + kh) = lo;
+                    }
+                } else {
+                    // lane = channel l31, registers = keys (r & 3) + 8 (r >> 2) + 4 kh: registers 8 s .. 8 s + 7 = unit (s, kh, l31)
+                    const int co = co0 + wco * 64 + i * 32 + l31;
+                    const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        uint4 hi, lo;
+                        float v[8];
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) v[m] = (acc[i][j][8 * st + m] * us + bv) * os;
+                        qkv_split2(v[0], v[1], hi.x, lo.x);
+                        qkv_split2(v[2], v[3], hi.y, lo.y);
+                        qkv_split2(v[4], v[5], hi.z, lo.z);
+                        qkv_split2(v[6], v[7], hi.w, lo.w);
+                        *reinterpret_cast<uint4*>(&tile[512 + (st * 2 + kh) * 32 + l31]) = hi;
+                        *reinterpret_cast<uint4*>(&tile[640 + (st * 2 + kh) * 32 + l31]) = lo;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const int co_lane = co0 + wco * 64 + 4 * kh;
     float bias_r[2][16];
 #pragma unroll
@@ -187,7 +270,33 @@ extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, c
     if ((const half8*)wp_lo != a.wh + (long long)a.Cib * a.Cop) return LC_EINVAL;    // one allocation, lo behind hi
     a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
     a.Co = Co; a.out_scale = out_scale; a.range = range; a.wmeta = wmeta;
+    a.kv = nullptr; a.C = a.kv_heads = a.kv_tiles = 0;
     dim3 grid((unsigned)(B * ((P + P1::BP - 1) / P1::BP)), (unsigned)((Co + P1::BN - 1) / P1::BN));
-    hipLaunchKernelGGL(conv1x1_ps_kernel, grid, dim3(P1::NT), 0, lc_s(s), a);
+    hipLaunchKernelGGL(conv1x1_ps_kernel<false>, grid, dim3(P1::NT), 0, lc_s(s), a);
+    return lc_launch_status();
+}
+
+// The qkv projection of ObjectAwareCrossAttention (layout_unet_v1.py:416-430: conv_nd(1, C, 3 C, 1) on the normalised
+// tokens) with its keys and values written in the attention kernel's unit form: q [B][C][P] fp32 as before; rows C .. 3 C
+// never reach memory as fp32.  C % 128 == 0, 32 channels per head (heads = C / 32), P % 32 == 0; kv as
+// lc_attention_units_elems(B, C / 32, P, Lk1) describes it (the image keys are tiles 0 .. P / 32 - 1).
+extern "C" int lc_conv1x1_f16x2_ps_qkv_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias,
+                                           float* q, int64_t q_bs, void* kv, int B, int Ci, int C, int H, int W, int Lk1,
+                                           const float* wmeta, lc_conv_range* range, lc_stream_t s) {
+    if (!x_split || !wp_hi || !wp_lo || !q || !kv || !wmeta || !range || B <= 0 || Ci <= 0 || C <= 0 || H <= 0 || W <= 0)
+        return LC_EINVAL;
+    const long long P = (long long)H * W;
+    if (Ci % 32 || C % 128 || P % 32 || Lk1 < 0 || Lk1 > 32) return LC_EUNSUP;
+    const int Co = 3 * C;
+    if (P >= (1 << 24) || 2 * (Ci / 8) * P * 16 >= (1ll << 31) || (long long)C * P * 4 >= (1ll << 31)) return LC_EUNSUP;
+    P1Args a;
+    a.xsp = (const half8*)x_split; a.C8 = Ci / 8; a.P = (int)P; a.xsp_bs = 2ll * (Ci / 8) * P;
+    a.wh = (const half8*)wp_hi; a.Cib = Ci / 8; a.Cop = (Co + 63) / 64 * 64;
+    if ((const half8*)wp_lo != a.wh + (long long)a.Cib * a.Cop) return LC_EINVAL;
+    a.bias = bias; a.res = nullptr; a.res_bs = 0; a.y = q; a.y_bs = q_bs;
+    a.Co = Co; a.out_scale = 1.0f; a.range = range; a.wmeta = wmeta;
+    a.kv = (half8*)kv; a.C = C; a.kv_heads = C / 32; a.kv_tiles = (int)(P / 32) + (Lk1 > 0);
+    dim3 grid((unsigned)(B * ((P + P1::BP - 1) / P1::BP)), (unsigned)(Co / P1::BN));
+    hipLaunchKernelGGL(conv1x1_ps_kernel<true>, grid, dim3(P1::NT), 0, lc_s(s), a);
     return lc_launch_status();
 }

@@ -194,7 +194,7 @@ inline int grid_for(long long n) {
 
 }  // namespace
 
-extern "C" int lc_abi_version(void) { return 3; }
+extern "C" int lc_abi_version(void) { return 4; }
 
 extern "C" int64_t lc_calibrate_mfma_f16(const void* operands, int blocks, int iters, float* sink, lc_stream_t s) {
     if (!operands || !sink || blocks <= 0 || iters <= 0) return LC_EINVAL;

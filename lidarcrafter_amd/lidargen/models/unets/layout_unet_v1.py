@@ -210,8 +210,29 @@ class ObjectAwareCrossAttention(nn.Module):
             # a different condition while it is valid (versions are not tracked in inference mode)
             hold = (img, cond["obj_bbox_embedding"], cond["xf_out"], cond["obj_class_embedding"], mask)
             ops4 = self._refill(self._cond_cache, (pos_img, pos_lay, k_lay, v_lay), per_sample)
-            self._cond_cache = (key,) + ops4 + (per_sample, hold, itag)
+            units = self._static_units(self._cond_cache, ops4, per_sample)
+            self._cond_cache = (key,) + ops4 + (per_sample, hold, itag, units)
         return self._cond_cache[1:6]
+
+    def _static_units(self, old, ops4, per_sample):
+        """Keys / values in the attention kernel's unit form (ops.AttnUnits): the positional channels of every key and the
+        layout keys / values are step-invariant -- split and packed here, once per condition; the content channels of the
+        image keys and the image values are written per step by the qkv projection's epilogue (forward)."""
+        pos_img, pos_lay, k_lay, v_lay = ops4
+        B, _, L1 = pos_img.shape
+        heads, C = self.num_heads, self.channels
+        dqk, dpos, L2 = C // heads, self.pos_channels // heads, k_lay.shape[-1]
+        if per_sample is not None or not pos_img.is_cuda or not K.AttnUnits.eligible(heads, L1, L2, dqk, dpos, dqk):
+            return None
+        u = old[8] if old is not None and len(old) > 8 else None
+        if u is None or not u.fits(B, heads, L1, L2, dqk, dpos, dqk, pos_img.device) or not torch.is_inference_mode_enabled() \
+                or not u.buf.is_inference():
+            u = K.AttnUnits(B, heads, L1, L2, dqk, dpos, dqk, pos_img.device)
+        K.attention_pack_units(u, pos_img, "k_pos")
+        K.attention_pack_units(u, k_lay, "k", segment=1)
+        K.attention_pack_units(u, pos_lay, "k_pos", segment=1)
+        K.attention_pack_units(u, v_lay, "v", segment=1)
+        return u
 
     def _refill(self, old, new4, per_sample):
         """The operands of a NEW condition go into the tensors of the previous one when they fit (same shapes, inside a
@@ -238,6 +259,27 @@ class ObjectAwareCrossAttention(nn.Module):
         else:
             xs = x.contiguous().view(B, C, L1)
         pos_img, pos_lay, k_lay, v_lay, per_sample = self.condition_operands(cond_kwargs)
+        heads = self.num_heads
+        # (q*s)(k*s) with s = (((1 + scale_pos) C) / heads)^-1/4, :489-492
+        scale = 1.0 / math.sqrt(int((1 + self.channels_scale_for_positional_embedding) * C) // heads)
+        units = self._cond_cache[8] if K.ATTN_UNITS and K.ATTN_PRECISION == "f16x2" else None
+        if units is not None and units.B == B:
+            # keys and values in unit form: split once per step (by the projection's own epilogue where its tile fits the
+            # heads, else by one pass over k and one over v) instead of once per query block inside the attention kernel
+            if K.presplit_1x1(C, 3 * C, self.norm_for_qkv.num_groups) and K.qkv_units_ok(C, heads, L1):
+                xsplit = self.norm_for_qkv(xs, split_for=self.qkv_projector._packed)
+                q = K.qkv_project_units(xsplit, self.qkv_projector._packed, self.qkv_projector.weight,
+                                        self.qkv_projector.bias, units)
+            else:
+                if K.fuse_gn(3 * C):
+                    qkv = self.qkv_projector(xs, gn_coeffs=gn32_coeffs(self.norm_for_qkv, xs))
+                else:
+                    qkv = self.qkv_projector(self.norm_for_qkv(xs))
+                q = qkv[:, :C]
+                K.attention_pack_units(units, qkv[:, C:2 * C], "k")
+                K.attention_pack_units(units, qkv[:, 2 * C:], "v")
+            a = K.attention_units(q, units, heads, scale, q_pos=pos_img)
+            return self._project_out(x, xs, a, out, pos_img, pos_lay)
         if K.presplit_1x1(C, 3 * C, self.norm_for_qkv.num_groups):
             # many output channels: the norm writes hi / lo planes once, the projection stages them by LDS-DMA
             qkv = self.qkv_projector(self.norm_for_qkv(xs, split_for=self.qkv_projector._packed))
@@ -245,9 +287,6 @@ class ObjectAwareCrossAttention(nn.Module):
             qkv = self.qkv_projector(xs, gn_coeffs=gn32_coeffs(self.norm_for_qkv, xs))
         else:
             qkv = self.qkv_projector(self.norm_for_qkv(xs))
-        heads = self.num_heads
-        # (q*s)(k*s) with s = (((1 + scale_pos) C) / heads)^-1/4, :489-492
-        scale = 1.0 / math.sqrt(int((1 + self.channels_scale_for_positional_embedding) * C) // heads)
         if per_sample is None:
             a = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale,
                                k2=k_lay, v2=v_lay, q_pos=pos_img, k_pos=pos_img, k2_pos=pos_lay)
@@ -258,6 +297,11 @@ class ObjectAwareCrossAttention(nn.Module):
                 kl, vl, pl = per_sample[b] if per_sample[b] is not None else (None, None, None)
                 K.attention_cm(qkv[sl, :C], qkv[sl, C:2 * C], qkv[sl, 2 * C:], heads, scale, k2=kl, v2=vl,
                                q_pos=pos_img[sl], k_pos=pos_img[sl], k2_pos=pl, out=a[sl])
+        return self._project_out(x, xs, a, out, pos_img, pos_lay)
+
+    def _project_out(self, x, xs, a, out, pos_img, pos_lay):
+        B, C, H, W = x.shape
+        L1, heads = H * W, self.num_heads
         o3 = None if out is None else out
         # (statistics for the next block's GroupNorm: they follow the tensor through the token view)
         y = self.proj_out(a, res=xs, out=None if o3 is None else K.alias(_as3(o3), o3), emit_stats=True)
@@ -459,6 +503,8 @@ class LayoutUnetV1(nn.Module):
             if c is None or c[5] is not None:
                 return None
             out.extend(c[1:5])
+            if len(c) > 8 and c[8] is not None:
+                out.append(c[8].buf)                 # keys / values in unit form (static parts + the per-step rows)
         return out
 
     def _bind_concat(self, buf, cc, cx):

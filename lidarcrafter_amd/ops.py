@@ -1494,6 +1494,104 @@ def attention_cm(q, k, v, heads: int, scale: float, k2=None, v2=None, q_pos=None
     return out
 
 
+# Keys / values in unit form (csrc/attention_units.hip): the fp16 hi / lo split of the attention operands made once per
+# step -- or once per CONDITION for the step-invariant parts -- instead of once per query block inside the kernel.
+# LC_ATTN_UNITS=0 keeps ObjectAwareCrossAttention on lc_attention_f16x2_fwd.
+ATTN_UNITS = _os.environ.get("LC_ATTN_UNITS", "1") != "0"
+
+
+class AttnUnits:
+    """K / V of one attention layer in unit form: `buf` [B, heads, tiles, 768 * 8] halves (zero where a head has no
+    channel or key).  Image keys first (Lk0, a multiple of 32), then one tile of up to 32 further keys (Lk1)."""
+
+    __slots__ = ("buf", "B", "heads", "Lk0", "Lk1", "dqk", "dpos", "dv")
+
+    def __init__(self, B, heads, Lk0, Lk1, dqk, dpos, dv, device):
+        n = lib().lc_attention_units_elems(B, heads, Lk0, Lk1)
+        if n < 0 or dqk % 8 or dpos % 8 or dqk + dpos > 64 or dv > 32:
+            raise ValueError("attention units: Lk0 % 32 == 0, Lk1 <= 32, dqk / dpos multiples of 8 with dqk + dpos <= 64, dv <= 32")
+        self.buf = torch.zeros((B, heads, Lk0 // 32 + (1 if Lk1 > 0 else 0), 768 * 8), device=device, dtype=torch.float16)
+        self.B, self.heads, self.Lk0, self.Lk1, self.dqk, self.dpos, self.dv = B, heads, Lk0, Lk1, dqk, dpos, dv
+
+    @staticmethod
+    def eligible(heads, Lk0, Lk1, dqk, dpos, dv) -> bool:
+        return (ATTN_UNITS and ATTN_PRECISION == "f16x2" and Lk0 % 32 == 0 and 0 <= Lk1 <= 32 and dqk % 8 == 0
+                and dpos % 8 == 0 and 32 < dqk + dpos <= 64 and dv <= 32)
+
+    def fits(self, B, heads, Lk0, Lk1, dqk, dpos, dv, device) -> bool:
+        return (self.B, self.heads, self.Lk0, self.Lk1, self.dqk, self.dpos, self.dv, self.buf.device) == \
+            (B, heads, Lk0, Lk1, dqk, dpos, dv, device)
+
+
+def _cm_operand(t, d):
+    from ._lib import CmOperand
+    import ctypes as C
+
+    _req(t, "operand")
+    if t.dim() != 3 or (t.shape[2] > 1 and t.stride(2) != 1):
+        raise ValueError("attention: operands must be [B,C,L] with unit token stride")
+    return C.byref(CmOperand(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else 0, d * t.stride(1), t.stride(1)))
+
+
+def attention_pack_units(units: AttnUnits, src: torch.Tensor, what: str, segment: int = 0) -> None:
+    """Write one operand into the unit form.  what: "k" (content channels of the keys), "k_pos" (their positional
+    channels), "v"; segment 0 = the image keys [0, Lk0), 1 = the extra tile (layout keys).  src: [B, heads * d, L] fp32
+    (batch stride 0 allowed), split with the constants of lc_attention_f16x2_fwd."""
+    u = units
+    d = {"k": u.dqk, "k_pos": u.dpos, "v": u.dv}[what]
+    L = u.Lk0 if segment == 0 else u.Lk1
+    if src.shape[1] != u.heads * d or src.shape[2] != L or src.shape[0] not in (1, u.B):
+        raise ValueError(f"attention_pack_units: `{what}` of segment {segment} must be [{u.B}, {u.heads * d}, {L}], got {tuple(src.shape)}")
+    check(lib().lc_attention_pack_units(_cm_operand(src, d), u.buf.data_ptr(), u.B, u.heads, L, u.Lk0, u.Lk1, d,
+                                        u.dqk // 8 if what == "k_pos" else 0, 0 if segment == 0 else u.Lk0,
+                                        1 if what == "v" else 0, _stream()), "lc_attention_pack_units")
+
+
+def qkv_project_units(xs: SplitAct, packed: PackedConv, weight: torch.Tensor, bias, units: AttnUnits) -> torch.Tensor:
+    """The qkv projection (1x1, C -> 3 C) of a pre-split token tensor with its keys and values written straight into
+    `units` (image-key segment): returns q [B, C, L] fp32; k and v never exist as fp32 tensors
+    (lc_conv1x1_f16x2_ps_qkv_fwd).  32 channels per head, C % 128 == 0."""
+    if xs.packed is not packed:
+        raise ValueError("conv: the pre-split activation was produced for another layer")
+    wh, wl = packed.get_f16x2(weight)
+    B, Ci, H, W = xs.shape
+    C, u = packed.Co // 3, units
+    if packed.ks != 1 or packed.Co != 3 * C or Ci != packed.Ci or (u.B, u.heads * 32, u.Lk0, u.dqk, u.dv) != (B, C, H * W, 32, 32):
+        raise ValueError("qkv_project_units: a 1x1 projection C -> 3 C onto units of C / 32 heads over H * W keys")
+    if bias is not None:
+        _req(bias, "bias")
+    q = torch.empty((B, C, H * W), device=xs.buf.device, dtype=_F32)
+    with _Timed("conv1x1", 2.0 * B * H * W * 3 * C * Ci):
+        check(_conv_lib().lc_conv1x1_f16x2_ps_qkv_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(), _p(bias), q.data_ptr(),
+                                                      q.stride(0), u.buf.data_ptr(), B, Ci, C, H, W, u.Lk1,
+                                                      packed.wmeta.data_ptr(), packed.range_ptr(xs.buf.device), _stream()),
+              "lc_conv1x1_f16x2_ps_qkv_fwd")
+    return q
+
+
+def qkv_units_ok(C: int, heads: int, L: int) -> bool:
+    """Can the qkv projection write the unit form itself?  (else: lc_attention_pack_units after a plain projection)"""
+    return C % 128 == 0 and C == 32 * heads and L % 32 == 0
+
+
+def attention_units(q, units: AttnUnits, heads: int, scale: float, q_pos=None, out: Optional[torch.Tensor] = None):
+    """attention_cm(q, k, v, ..., k2, v2, q_pos, k_pos, k2_pos) with the keys and values taken from `units`: the same
+    arithmetic, bit for bit (the split happens in the writers of the units instead of the attention kernel)."""
+    u = units
+    B, Cq, Lq = q.shape
+    dpos = 0 if q_pos is None else q_pos.shape[1] // heads
+    if heads != u.heads or B != u.B or Cq // heads != u.dqk or dpos != u.dpos:
+        raise ValueError("attention_units: q does not match the units")
+    if out is None:
+        out = torch.empty((B, heads * u.dv, Lq), device=q.device, dtype=_F32)
+    with _Timed("attention", 2.0 * B * heads * Lq * (u.Lk0 + u.Lk1) * (u.dqk + dpos + u.dv)):
+        check(lib().lc_attention_units_fwd(_cm_operand(q, u.dqk), None if q_pos is None else _cm_operand(q_pos, dpos),
+                                           u.buf.data_ptr(), out.data_ptr(), out.stride(0), u.dv * out.stride(1),
+                                           out.stride(1), B, heads, Lq, u.Lk0, u.Lk1, u.dqk, dpos, u.dv, float(scale),
+                                           _stream()), "lc_attention_units_fwd")
+    return out
+
+
 # ------------------------------------------------------------------------------------ sampler
 def pstep(x_t, pred, noise, coef, objective: int, mode: int, out=None) -> torch.Tensor:
     xb, pb = _bs4(x_t, "x_t"), _bs4(pred, "pred")

@@ -660,6 +660,93 @@ def test_attention_two_segments_and_spike(dev, prec, B, heads, L1):
     assert rel_l2(o, ref) < ATTN_TOL[prec], rel_l2(o, ref)
 
 
+@pytest.mark.parametrize("B,heads,Lq,Lk0,Lk1,dqk,dpos,dv", [
+    (2, 3, 192, 192, 13, 32, 32, 32),      # ObjectAwareCrossAttention's shape in small: image keys ++ 13 layout keys
+    (8, 8, 512, 512, 13, 32, 32, 32),      # the 8-wave block (ds 8 of the layout model)
+    (2, 2, 100, 128, 0, 40, 16, 24),       # ragged queries, no second segment, channels a head does not fill
+    (1, 2, 64, 64, 32, 64, 0, 8),          # no positional part, a full second tile
+])
+def test_attention_units_bit_equal(dev, B, heads, Lq, Lk0, Lk1, dqk, dpos, dv):
+    """Keys / values in unit form (csrc/attention_units.hip: split once by lc_attention_pack_units, staged by LDS-DMA)
+    against lc_attention_f16x2_fwd on the same operands: the same arithmetic, so the same bits -- and both within the
+    f16x2 tolerance of the float64 softmax."""
+    from lidarcrafter_amd import ops as K
+
+    mk = lambda c, L, seed: seeded_randn(B, heads * c, L, seed=seed).to(dev)
+    q, k, v = mk(dqk, Lq, 61), mk(dqk, Lk0, 62), mk(dv, Lk0, 63)
+    qp = mk(dpos, Lq, 64) if dpos else None
+    kp = seeded_randn(1, heads * dpos, Lk0, seed=65).to(dev).expand(B, -1, -1) if dpos else None   # stride-0 batch
+    k2 = mk(dqk, Lk1, 66) if Lk1 else None
+    v2 = mk(dv, Lk1, 67) if Lk1 else None
+    k2p = mk(dpos, Lk1, 68) if (Lk1 and dpos) else None
+    k[:, :, Lk0 - 7] = 2.5 * q[:, :, 3] if Lq == Lk0 else k[:, :, Lk0 - 7]     # a late spike: the running maximum moves
+    scale = (dqk + dpos) ** -0.5
+    want = K.attention_cm(q, k, v, heads, scale, k2=k2, v2=v2, q_pos=qp, k_pos=kp, k2_pos=k2p, precision="f16x2")
+    assert K.AttnUnits.eligible(heads, Lk0, Lk1, dqk, dpos, dv)
+    u = K.AttnUnits(B, heads, Lk0, Lk1, dqk, dpos, dv, dev)
+    K.attention_pack_units(u, k, "k"), K.attention_pack_units(u, v, "v")
+    if dpos:
+        K.attention_pack_units(u, kp, "k_pos")
+    if Lk1:
+        K.attention_pack_units(u, k2, "k", segment=1), K.attention_pack_units(u, v2, "v", segment=1)
+        if dpos:
+            K.attention_pack_units(u, k2p, "k_pos", segment=1)
+    got = K.attention_units(q, u, heads, scale, q_pos=qp)
+    assert torch.equal(got, want)
+    # a second step: new content keys / values over the old ones, the static parts stay
+    k_, v_ = mk(dqk, Lk0, 72), mk(dv, Lk0, 73)
+    K.attention_pack_units(u, k_, "k"), K.attention_pack_units(u, v_, "v")
+    assert torch.equal(K.attention_units(q, u, heads, scale, q_pos=qp),
+                       K.attention_cm(q, k_, v_, heads, scale, k2=k2, v2=v2, q_pos=qp, k_pos=kp, k2_pos=k2p))
+    qh = torch.cat([t.reshape(B, heads, -1, Lq) for t in (q, qp) if t is not None], 2).double().cpu()
+    k0 = torch.cat([t.reshape(B, heads, -1, Lk0) for t in (k, kp) if t is not None], 2)
+    kh, vh = k0, v.reshape(B, heads, dv, Lk0)
+    if Lk1:
+        k1 = torch.cat([t.reshape(B, heads, -1, Lk1) for t in (k2, k2p) if t is not None], 2)
+        kh, vh = torch.cat([k0, k1], -1), torch.cat([vh, v2.reshape(B, heads, dv, Lk1)], -1)
+    sc = torch.einsum("bhct,bhcs->bhts", qh, kh.double().cpu()) * scale
+    ref = torch.einsum("bhts,bhcs->bhct", sc.softmax(-1), vh.double().cpu()).reshape(B, heads * dv, Lq)
+    assert rel_l2(want, ref) < ATTN_TOL["f16x2"]
+
+
+@pytest.mark.parametrize("B,C,L,L2", [(2, 256, 512, 13), (8, 256, 2048, 13), (1, 128, 96, 0), (2, 512, 128, 13)])
+def test_qkv_projection_writes_units(dev, monkeypatch, B, C, L, L2):
+    """lc_conv1x1_f16x2_ps_qkv_fwd: the qkv projection whose key / value rows leave the kernel in the attention kernel's
+    unit form (values through transposed accumulators) against the plain projection + lc_attention_f16x2_fwd."""
+    from lidarcrafter_amd import ops as K
+    from lidargen.models.unets.nn import GroupNorm32, PointwiseConv1d
+
+    monkeypatch.setattr(K, "PS1X1_MIN_CO", 128)
+    heads, d = C // 32, 32
+    norm = seeded_fill(GroupNorm32(32, C), salt=41).to(dev)
+    proj = seeded_fill(PointwiseConv1d(C, 3 * C), salt=42).to(dev)
+    x = seeded_randn(B, C, L, seed=43).to(dev)
+    pos = seeded_randn(1, heads * d, L, seed=44).to(dev).expand(B, -1, -1)
+    k2 = seeded_randn(B, C, L2, seed=45).to(dev) if L2 else None
+    v2 = seeded_randn(B, C, L2, seed=46).to(dev) if L2 else None
+    k2p = seeded_randn(B, C, L2, seed=47).to(dev) if L2 else None
+    scale = (2 * d) ** -0.5
+    with torch.no_grad():
+        assert K.presplit_1x1(C, 3 * C, 32) and K.qkv_units_ok(C, heads, L)
+        qkv = proj(norm(x, split_for=proj._packed))
+        want = K.attention_cm(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, scale, k2=k2, v2=v2, q_pos=pos, k_pos=pos,
+                              k2_pos=k2p)
+        u = K.AttnUnits(B, heads, L, L2, d, d, d, dev)
+        K.attention_pack_units(u, pos, "k_pos")
+        if L2:
+            K.attention_pack_units(u, k2, "k", 1), K.attention_pack_units(u, v2, "v", 1), K.attention_pack_units(u, k2p, "k_pos", 1)
+        q = K.qkv_project_units(norm(x, split_for=proj._packed), proj._packed, proj.weight, proj.bias, u)
+        assert torch.equal(q, qkv[:, :C])
+        # the units the epilogue wrote == the units packed from the fp32 rows of the plain projection
+        u2 = K.AttnUnits(B, heads, L, L2, d, d, d, dev)
+        K.attention_pack_units(u2, pos, "k_pos"), K.attention_pack_units(u2, qkv[:, C:2 * C], "k"), K.attention_pack_units(u2, qkv[:, 2 * C:], "v")
+        if L2:
+            K.attention_pack_units(u2, k2, "k", 1), K.attention_pack_units(u2, v2, "v", 1), K.attention_pack_units(u2, k2p, "k_pos", 1)
+        assert torch.equal(u.buf, u2.buf)
+        got = K.attention_units(q, u, heads, scale, q_pos=pos)
+    assert torch.equal(got, want)
+
+
 # ------------------------------------------------------------------------------------- sampler
 def test_pstep_golden(dev, golden):
     from lidargen.models.diffusion import ContinuousTimeGaussianDiffusion
