@@ -15,17 +15,23 @@
 // * out_scale.  Needs Ci % 32 == 0.  First measurement (the candidate's harness of round 5): GroupNorm + projection
 // 256 -> 768 @ 8 x 256, batch 8: 74.9 -> 54.4 us; 512 -> 1536 @ 4 x 128: 64.8 -> 39.9 us.
 #pragma once
+#include <type_traits>
 
 namespace {
 
-struct P1 {
-    static constexpr int BN = 128, BP = 256, CBK = 4, NT = 512;
+// BPV = pixels per block: 256 (8 waves, 2 x 48 KB of LDS: one block per CU) or 128 (4 waves, 2 x 32 KB: two blocks per CU --
+// the shapes whose 256-pixel grid leaves CUs idle or runs a half-empty second round, e.g. 512 -> 1536 @ 4 x 128 at batch 8:
+// 192 blocks on 256 CUs)
+template <int BPV>
+struct P1T {
+    static constexpr int BN = 128, BP = BPV, CBK = 4, NWV = 2 * (BPV / 64), NT = 64 * NWV;
     static constexpr int XS = CBK * BP, WS = CBK * BN;            // units per plane per buffer
-    static constexpr int BUF = 2 * XS + 2 * WS;                   // 48 KB
-    static constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk: 32 + 16
-    static constexpr int IPW = (NX + NW) / 8;                     // per wave: 6
-    static_assert(NX % 8 == 0 && NW % 8 == 0, "the kind of a DMA slot must not depend on the wave");
+    static constexpr int BUF = 2 * XS + 2 * WS;                   // 48 KB / 32 KB
+    static constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk: 32 + 16 / 16 + 16
+    static constexpr int IPW = (NX + NW) / NWV;                   // per wave: 6 / 8
+    static_assert(NX % NWV == 0 && NW % NWV == 0, "the kind of a DMA slot must not depend on the wave");
 };
+using P1 = P1T<256>;
 
 struct P1Args {
     const half8* xsp; long long xsp_bs; int C8, P;
@@ -53,15 +59,16 @@ __device__ __forceinline__ void qkv_split2(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
 }
 
-template <bool QKV>
-__global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
+template <bool QKV, int BPV = 256>
+__global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_kernel(P1Args a) {
+    using P1 = P1T<BPV>;
     constexpr int BN = P1::BN, BP = P1::BP, CBK = P1::CBK, XS = P1::XS, WS = P1::WS, BUF = P1::BUF;
-    constexpr int NX = P1::NX, NW = P1::NW, IPW = P1::IPW;
+    constexpr int NX = P1::NX, NW = P1::NW, IPW = P1::IPW, NWV = P1::NWV, WPX = BP / 64;
     constexpr unsigned OOB = 0x80000000u;
     __shared__ half8 lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave >> 2, wpx = wave & 3;
+    const int wco = wave / WPX, wpx = wave % WPX;
     const int tiles_p = (a.P + BP - 1) / BP;
     const int b = blockIdx.x / tiles_p, p0 = (blockIdx.x - b * tiles_p) * BP;
     const int co0 = blockIdx.y * BN;
@@ -77,8 +84,8 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
     int ldsoff[IPW];
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
-        const int j = wave + 8 * k;
-        if (k < NX / 8) {
+        const int j = wave + NWV * k;
+        if (k < NX / NWV) {
             const int plane = j / (NX / 2), rem = j - plane * (NX / 2);
             const int cb = rem / (BP / 64), q = rem - cb * (BP / 64);
             const int p = p0 + q * 64 + lane;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
     auto issue = [&](half8* buf, int ch) {
 #pragma unroll
         for (int k = 0; k < IPW; ++k)
-            if (k < NX / 8) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
+            if (k < NX / NWV) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
             else lds_dma16(rs_w, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * w_chunk);
     };
 
@@ -119,54 +126,67 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
     issue(cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        if (ch + 1 < nchunk) issue(nxt, ch + 1);          // lands while this chunk's MFMAs run
-        const half8* xh = cur;
-        const half8* xl = cur + XS;
-        const half8* wh = cur + 2 * XS;
-        const half8* wl = wh + WS;
+    // (the whole K loop exists twice in a QKV kernel: a branch around each k-step's MFMAs keeps hipcc from interleaving
+    //  the fragment reads of one k-step with the MFMAs of the other -- measured +11 us at 512 -> 1536 @ 4 x 128)
+    auto k_loop = [&](auto transposed) {
+        constexpr bool VT = decltype(transposed)::value;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (ch + 1 < nchunk) issue(nxt, ch + 1);          // lands while this chunk's MFMAs run
+            const half8* xh = cur;
+            const half8* xl = cur + XS;
+            const half8* wh = cur + 2 * XS;
+            const half8* wl = wh + WS;
 #pragma unroll
-        for (int ks = 0; ks < CBK / 2; ++ks) {
-            half8 ah[2], al[2], bh[2], bl[2];
+            for (int ks = 0; ks < CBK / 2; ++ks) {
+                half8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = wh[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
-                al[i] = wl[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
-            }
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = wh[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
+                    al[i] = wl[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
+                }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[j] = xh[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
-                bl[j] = xl[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
-            }
-            if (QKV && vt) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                        if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-                    }
-            } else {
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = xh[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
+                    bl[j] = xl[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        if (VT) {
+                            if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                            if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                        } else {
+                            if (LC_F16X2_TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            if (LC_F16X2_TERMS & 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
                     }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            half8* t = cur; cur = nxt; nxt = t;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        half8* t = cur; cur = nxt; nxt = t;
-    }
+    };
+    if (QKV && vt) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // ---- epilogue: accumulator register r of a lane = channel (r & 3) + 8 (r >> 2) + 4 kh of the 32, pixel l31 ----------
     const float out_unscale = a.range->x_unscale * a.wmeta[1];
     float* yb = a.y + (long long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
+    const int co_lane = co0 + wco * 64 + 4 * kh;
+    float bias_r[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
+            // (QKV value blocks: the accumulators are transposed, a lane owns ONE channel per 32-block)
+            const int cb_ = (QKV && vt) ? co0 + wco * 64 + i * 32 + l31 : co;
+            bias_r[i][r] = (a.bias && cb_ < a.Co) ? a.bias[cb_] : 0.0f;
+        }
     if (QKV && co0 >= a.C) {
         // ---- keys / values -> unit form.  Tile image (768 units): K hi [cb 8][key 32] | K lo | V hi [step 2][half 2][c 32] | V lo
         const float us = out_unscale, os = a.out_scale;
@@ -186,10 +206,7 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
                     for (int cb = 0; cb < 4; ++cb) {
                         float v[4];
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const int co = co0 + wco * 64 + i * 32 + 8 * cb + 4 * kh + m;
-                            v[m] = (acc[i][j][4 * cb + m] * us + (a.bias ? a.bias[co] : 0.0f)) * os;
-                        }
+                        for (int m = 0; m < 4; ++m) v[m] = (acc[i][j][4 * cb + m] * us + bias_r[i][4 * cb + m]) * os;
                         uint2 hi, lo;
                         qkv_split2(v[0], v[1], hi.x, lo.x);
                         qkv_split2(v[2], v[3], hi.y, lo.y);
@@ -198,8 +215,7 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
                     }
                 } else {
                     // lane = channel l31, registers = keys (r & 3) + 8 (r >> 2) + 4 kh: registers 8 s .. 8 s + 7 = unit (s, kh, l31)
-                    const int co = co0 + wco * 64 + i * 32 + l31;
-                    const float bv = a.bias ? a.bias[co] : 0.0f;
+                    const float bv = bias_r[i][0];
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
                         uint4 hi, lo;
@@ -218,15 +234,6 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
         }
         return;
     }
-    const int co_lane = co0 + wco * 64 + 4 * kh;
-    float bias_r[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
-            bias_r[i][r] = (a.bias && co < a.Co) ? a.bias[co] : 0.0f;
-        }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int p = p0 + wpx * 64 + j * 32 + l31;
@@ -253,6 +260,16 @@ __global__ __launch_bounds__(P1::NT, 1) void conv1x1_ps_kernel(P1Args a) {
 
 }  // namespace
 
+// 128-pixel blocks (two per CU) where the 256-pixel grid does not fill the chip once (512 -> 1536 @ 4 x 128 at batch 8: 192
+// blocks, 48 -> 43 us inside a step); LC_P1_BP=128 / 256 forces one
+static bool p1_small_tile(int B, long long P, int Co) {
+    static const int env = [] { const char* e = getenv("LC_P1_BP"); return e ? atoi(e) : 0; }();
+    if (env == 128) return true;
+    if (env == 256) return false;
+    const long long blocks256 = (long long)B * ((P + 255) / 256) * ((Co + 127) / 128);
+    return blocks256 <= 256;      // (384 blocks -- 256 -> 768 @ 8 x 256 at batch 8 -- measure 42 against 46.5 us inside a step)
+}
+
 // x_split: [B][2][Ci/8][P][8] halves as lc_groupnorm_apply*_split write them (P = H * W); wp_hi / wp_lo / wmeta: the ks = 1
 // pack of lc_pack_conv_weight_f16x2 (lo plane directly behind the hi plane); y, res: fp32 [B][Co][P] with batch strides.
 extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias,
@@ -271,6 +288,11 @@ extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, c
     a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
     a.Co = Co; a.out_scale = out_scale; a.range = range; a.wmeta = wmeta;
     a.kv = nullptr; a.C = a.kv_heads = a.kv_tiles = 0;
+    if (p1_small_tile(B, P, Co)) {
+        dim3 grid((unsigned)(B * ((P + 127) / 128)), (unsigned)((Co + P1::BN - 1) / P1::BN));
+        hipLaunchKernelGGL((conv1x1_ps_kernel<false, 128>), grid, dim3(P1T<128>::NT), 0, lc_s(s), a);
+        return lc_launch_status();
+    }
     dim3 grid((unsigned)(B * ((P + P1::BP - 1) / P1::BP)), (unsigned)((Co + P1::BN - 1) / P1::BN));
     hipLaunchKernelGGL(conv1x1_ps_kernel<false>, grid, dim3(P1::NT), 0, lc_s(s), a);
     return lc_launch_status();
@@ -296,6 +318,11 @@ extern "C" int lc_conv1x1_f16x2_ps_qkv_fwd(const void* x_split, const void* wp_h
     a.bias = bias; a.res = nullptr; a.res_bs = 0; a.y = q; a.y_bs = q_bs;
     a.Co = Co; a.out_scale = 1.0f; a.range = range; a.wmeta = wmeta;
     a.kv = (half8*)kv; a.C = C; a.kv_heads = C / 32; a.kv_tiles = (int)(P / 32) + (Lk1 > 0);
+    if (p1_small_tile(B, P, Co)) {
+        dim3 grid((unsigned)(B * ((P + 127) / 128)), (unsigned)(Co / P1::BN));
+        hipLaunchKernelGGL((conv1x1_ps_kernel<true, 128>), grid, dim3(P1T<128>::NT), 0, lc_s(s), a);
+        return lc_launch_status();
+    }
     dim3 grid((unsigned)(B * ((P + P1::BP - 1) / P1::BP)), (unsigned)(Co / P1::BN));
     hipLaunchKernelGGL(conv1x1_ps_kernel<true>, grid, dim3(P1::NT), 0, lc_s(s), a);
     return lc_launch_status();
