@@ -7,10 +7,13 @@ SURVEY.md §8a-16 keeps it in plain tensor ops; it is device agnostic (the refer
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch as th
 import torch.nn as nn
+
+CORE_GRAPH = os.environ.get("LC_ENCODER_GRAPH", "1") != "0"   # the layout-dependent core as one replayed HIP graph inside sampling runs
 
 
 class LayerNorm(nn.LayerNorm):
@@ -141,9 +144,30 @@ class LayoutTransformerEncoder(nn.Module):
                 is_valid_obj=None, image_patch_bbox=None):
         boxes = condition_dict["scaled_gt_boxes"]
         dev = boxes.device
+        core = self._core_by_graph(boxes, condition_dict["gt_boxes_2d"], condition_dict["is_valid_obj"])
+        out = core if core is not None else \
+            self._core(boxes, condition_dict["gt_boxes_2d"], condition_dict["is_valid_obj"], obj_mask)
+        if "obj_bbox" in self.used_condition_types:
+            for r in self.resolution_to_attention:
+                key = f"resolution{int(self.feature_map_size[0] / r)}"
+                emb, tag = self._patch_embedding(key, dev)                        # [hidden, L]
+                # same rows for every sample: a stride-0 batch view, not B copies
+                view = emb[None].expand(boxes.shape[0], -1, -1)
+                # (the rows depend on this module's weights only, not on the condition: a consumer that has
+                #  derived something from a view with the same tag need not derive it again --
+                #  ObjectAwareCrossAttention.condition_operands)
+                view._lc_weights_only = tag
+                out["image_patch_bbox_embedding_for_" + key] = view
+        if "concat_cond" in condition_dict:
+            cc = condition_dict["concat_cond"]
+            if "autoregressive_cond" in condition_dict:
+                cc = torch.cat([cc, condition_dict["autoregressive_cond"]], dim=1)
+            out["concat_cond"] = cc
+        return out
+
+    def _core(self, boxes, obj_bbox_2d, is_valid_obj, obj_mask=None):
+        """Everything that depends on the layout (reference layout_encoder.py:205-262): ~100 small launches on 13 tokens."""
         obj_bbox, obj_class = boxes[..., :8], boxes[..., -1]
-        obj_bbox_2d = condition_dict["gt_boxes_2d"]
-        is_valid_obj = condition_dict["is_valid_obj"]
         out, xf_in = {}, None
         if self.use_positional_embedding:
             xf_in = self.positional_embedding[None]
@@ -156,16 +180,6 @@ class LayoutTransformerEncoder(nn.Module):
             e2 = self.obj_bbox_2d_embedding(obj_bbox_2d.to(self.dtype))
             xf_in = e3 if xf_in is None else xf_in + e3 + e2
             out["obj_bbox_embedding"] = e2.permute(0, 2, 1).contiguous()
-            for r in self.resolution_to_attention:
-                key = f"resolution{int(self.feature_map_size[0] / r)}"
-                emb, tag = self._patch_embedding(key, dev)                        # [hidden, L]
-                # same rows for every sample: a stride-0 batch view, not B copies
-                view = emb[None].expand(e3.shape[0], -1, -1)
-                # (the rows depend on this module's weights only, not on the condition: a consumer that has
-                #  derived something from a view with the same tag need not derive it again --
-                #  ObjectAwareCrossAttention.condition_operands)
-                view._lc_weights_only = tag
-                out["image_patch_bbox_embedding_for_" + key] = view
         if "obj_mask" in self.used_condition_types:
             m = self.obj_mask_embedding(obj_mask.view(*obj_mask.shape[:2], -1).to(self.dtype))
             xf_in = m if xf_in is None else xf_in + m
@@ -179,9 +193,56 @@ class LayoutTransformerEncoder(nn.Module):
             xf_out = self.final_ln(xf_out)
         out["xf_proj"] = self.transformer_proj(xf_out[:, 0])
         out["xf_out"] = xf_out.permute(0, 2, 1).contiguous()
-        if "concat_cond" in condition_dict:
-            cc = condition_dict["concat_cond"]
-            if "autoregressive_cond" in condition_dict:
-                cc = torch.cat([cc, condition_dict["autoregressive_cond"]], dim=1)
-            out["concat_cond"] = cc
         return out
+
+    # The core is host-bound (1.8 ms for ~9 MFLOP) and runs once per `sample()` call while the GPU idles: inside a sampling
+    # run (inference mode) its inputs go through static copies and, from the second call of a shape on, ONE replayed HIP
+    # graph does the work; the results are handed out as fresh copies (a caller may hold several conditions at once).
+    def _core_by_graph(self, boxes, obj_bbox_2d, is_valid_obj):
+        if not (CORE_GRAPH and torch.is_inference_mode_enabled() and boxes.is_cuda and not self.use_key_padding_mask
+                and "obj_mask" not in self.used_condition_types and not torch.cuda.is_current_stream_capturing()
+                and not torch.is_autocast_enabled()):
+            return None
+        ins = (boxes, obj_bbox_2d, is_valid_obj)
+        fp = []
+        for t in self.parameters():
+            fp.append((t.data_ptr(), t._version))
+        sig = (tuple((tuple(t.shape), t.dtype, t.device) for t in ins), tuple(fp))
+        st = self.__dict__.get("_core_graph")
+        if st is None or st["sig"] != sig:
+            st = dict(sig=sig, inp=[t.clone() for t in ins], graph=None, out=None, runs=0)
+            self.__dict__["_core_graph"] = st
+        else:
+            for d, t in zip(st["inp"], ins):
+                d.copy_(t)
+        if st["graph"] is None and st["runs"] >= 1:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st["out"] = self._core(*st["inp"])
+                st["graph"] = g
+            except Exception as e:                  # an optimisation only
+                import warnings
+
+                warnings.warn(f"HIP graph capture of the layout encoder failed ({e!r}); staying eager")
+                st["graph"] = False
+        if st["graph"]:
+            st["graph"].replay()
+            return {k: v.clone() for k, v in st["out"].items()}
+        st["runs"] += 1
+        return self._core(*st["inp"])
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_core_graph" else copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_core_graph"] = None
+        return d

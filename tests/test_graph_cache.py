@@ -102,16 +102,23 @@ def test_layout_conditions_share_one_capture(dev, monkeypatch):
         b = {k: v.to(dev) for k, v in synth_layout_batch(2, 8, 64, seed=s).items()}
         b["concat_cond"] = torch.randn(2, 10, 8, 64, generator=torch.Generator().manual_seed(s)).to(dev)
         batches[s] = b
+    import lidargen.models.unets.layout_unet_v1 as LU
+
     run = lambda s, seed: ddpm.sample(dict(batches[s]), 2, 5, progress=False, rng=_gens(2, seed), mode="ddim")
+    # the reference runs: no graph kept across runs, the condition operands computed eagerly per run (rounds 1-5)
     monkeypatch.setattr(ddpm, "graph_cache_size", 0)
+    monkeypatch.setattr(LU, "PREPARE_GRAPH", False)
     ref = {(s, seed): run(s, seed) for s, seed in ((51, 0), (57, 0), (57, 4))}
     assert not torch.equal(ref[51, 0], ref[57, 0])              # the condition matters
+    assert ddpm.model.__dict__.get("_prep") is None
+    monkeypatch.setattr(LU, "PREPARE_GRAPH", True)
     monkeypatch.setattr(ddpm, "graph_cache_size", 4)
     cap = _Captures(ddpm, monkeypatch)
     assert torch.equal(run(51, 0), ref[51, 0]) and cap.n == 1
     assert torch.equal(run(57, 0), ref[57, 0]) and cap.n == 1   # new condition, old graph
     assert torch.equal(run(57, 4), ref[57, 4]) and cap.n == 1
     assert torch.equal(run(51, 0), ref[51, 0]) and cap.n == 1
+    assert ddpm.model._prep["graph"] is not None and ddpm.model._prep["graph"] is not False     # operands by one graph
     # the image-side positional operand is kept across conditions while the weights behind it stand still
     # (layout_encoder._patch_embedding's tag): move one of them -- operand and graph key must follow
     with torch.no_grad():
@@ -186,3 +193,32 @@ def test_sampler_copies_and_pickles_without_its_graphs(dev):
     assert torch.equal(twin.sample(2, 5, progress=False, rng=_gens(2, 1), mode="ddim"), x)
     buf = io.BytesIO()
     torch.save(ddpm, buf)
+
+
+def test_layout_encoder_core_by_graph(dev, monkeypatch):
+    """The layout-dependent core of the encoder as one replayed graph inside sampling runs (inference mode): same bits as
+    the eager core, fresh result tensors per call, weights followed."""
+    import lidargen.models.unets.layout_encoder as LE
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    _, enc = build_cond_pair((8, 64), 8, 32)
+    enc = enc.to(dev)
+    batches = [{k: v.to(dev) for k, v in synth_layout_batch(2, 8, 64, seed=s).items()} for s in (51, 57, 63)]
+    keys = ("xf_proj", "xf_out", "obj_class_embedding", "obj_bbox_embedding", "key_padding_mask")
+    with torch.inference_mode():
+        monkeypatch.setattr(LE, "CORE_GRAPH", False)
+        ref = [enc(b) for b in batches]
+        monkeypatch.setattr(LE, "CORE_GRAPH", True)
+        got = [enc(b) for b in batches] + [enc(batches[0])]
+        assert enc._core_graph["graph"]
+        for g, r in zip(got, ref + [ref[0]]):
+            assert set(g) == set(r)
+            for k in keys:
+                assert torch.equal(g[k], r[k]), k
+        assert got[1]["xf_out"].data_ptr() != got[2]["xf_out"].data_ptr()          # several conditions alive at once
+        assert not torch.equal(got[1]["xf_out"], got[2]["xf_out"])
+        with torch.inference_mode(False), torch.no_grad():
+            enc.transformer_proj.weight.mul_(2.0)
+        moved = enc(batches[0])
+        monkeypatch.setattr(LE, "CORE_GRAPH", False)
+        assert torch.equal(moved["xf_proj"], enc(batches[0])["xf_proj"]) and not torch.equal(moved["xf_proj"], ref[0]["xf_proj"])
