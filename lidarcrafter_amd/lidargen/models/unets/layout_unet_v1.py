@@ -537,7 +537,14 @@ class LayoutUnetV1(nn.Module):
         else:
             for k in self._PREP_KEYS:
                 st["inp"][k].copy_(lay[k])
-        lay.update(st["inp"])                      # the run reads the condition from the static inputs from here on
+        # the run reads the condition from the static inputs from here on: `forward` swaps THIS condition (recognised by the
+        # addresses of its three tensors, which `src` keeps alive) for the static view -- the caller's dict is left alone, it
+        # may be used again after other conditions have gone through the static inputs
+        st["src"] = tuple(lay[k] for k in self._PREP_KEYS)
+        st["src_id"] = tuple((t.data_ptr(), tuple(t.shape)) for t in st["src"])
+        lay = dict(lay)
+        lay.update(st["inp"])
+        st["lay"] = lay
         if st["graph"] is None and st["runs"] >= 1:
             try:
                 g = torch.cuda.CUDAGraph()
@@ -557,6 +564,15 @@ class LayoutUnetV1(nn.Module):
             m.condition_operands(lay, refresh=True)
         st["runs"] += 1
         return True
+
+    def _static_condition(self, lay):
+        """The static view of the condition `prepare_condition` last saw, when `lay` is that condition."""
+        st = self.__dict__.get("_prep")
+        if st is None or st.get("lay") is None or not all(k in lay for k in self._PREP_KEYS):
+            return lay
+        if tuple((lay[k].data_ptr(), tuple(lay[k].shape)) for k in self._PREP_KEYS) != st["src_id"]:
+            return lay
+        return st["lay"]
 
     def __deepcopy__(self, memo):
         # (a captured graph neither copies nor pickles: copy.deepcopy(ddpm) -- the reference trainers' EMA wrapper)
@@ -605,6 +621,7 @@ class LayoutUnetV1(nn.Module):
         if time_features is None and AG.training_active(self, x, lay.get("xf_proj"), lay.get("xf_out")):
             # training: the autograd graph over the HIP kernels (lidarcrafter_amd/autograd.py)
             return AG.layout_unet_v1_forward(self, x, cond_dict)
+        lay = self._static_condition(lay)
         B, cx, H, W = x.shape
         if time_features is None:
             t = cond_dict["time_condition"]

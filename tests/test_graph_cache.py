@@ -222,3 +222,38 @@ def test_layout_encoder_core_by_graph(dev, monkeypatch):
         moved = enc(batches[0])
         monkeypatch.setattr(LE, "CORE_GRAPH", False)
         assert torch.equal(moved["xf_proj"], enc(batches[0])["xf_proj"]) and not torch.equal(moved["xf_proj"], ref[0]["xf_proj"])
+
+
+def test_precomputed_conditions_reused_in_any_order(dev, monkeypatch):
+    """Condition dicts computed once and sampled from repeatedly, interleaved (A, B, A, B): the static inputs of the
+    operand graph never leak one condition into a dict that named another (the caller's dicts are left untouched)."""
+    import lidargen.models.unets.layout_unet_v1 as LU
+    from lidargen.models.diffusion import CondContinuousTimeGaussianDiffusion
+    from tests.test_oracle_vs_golden import build_cond_pair
+
+    m, enc = build_cond_pair((8, 64), 8, 32)
+    ddpm = CondContinuousTimeGaussianDiffusion(m, enc, cond_mode="concat").eval().to(dev)
+    batches = [{k: v.to(dev) for k, v in synth_layout_batch(2, 8, 64, seed=s).items()} for s in (51, 57)]
+
+    def run(cdict, seed):
+        with torch.inference_mode():
+            x_T = ddpm.randn(2, *ddpm.sampling_shape, rng=_gens(2, seed), device=ddpm.device)
+            st = ddpm.begin_sampling(2, 5, None, "ddim", 0.0, x_T=x_T, condition_dict=cdict)
+            for _ in range(5):
+                ddpm.sampling_step(st)
+            return st["x"].clone()
+
+    with torch.inference_mode():
+        conds = [ddpm.get_network_condition(input_dict=b, only_custom_condition=True) for b in batches]
+    ptrs = [{k: v.data_ptr() for k, v in c["other_condition"].items() if isinstance(v, torch.Tensor)} for c in conds]
+    monkeypatch.setattr(ddpm, "graph_cache_size", 0)
+    monkeypatch.setattr(LU, "PREPARE_GRAPH", False)
+    ref = [run(conds[0], 1), run(conds[1], 1)]
+    assert not torch.equal(ref[0], ref[1])
+    monkeypatch.setattr(LU, "PREPARE_GRAPH", True)
+    monkeypatch.setattr(ddpm, "graph_cache_size", 4)
+    for i in (0, 1, 0, 1, 1, 0):
+        assert torch.equal(run(conds[i], 1), ref[i]), i
+    assert ddpm.model._prep["graph"]
+    for c, p in zip(conds, ptrs):
+        assert {k: v.data_ptr() for k, v in c["other_condition"].items() if isinstance(v, torch.Tensor)} == p
