@@ -493,6 +493,14 @@ def main():
     srt = sorted(sweeps)
     dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
 
+    # the box's calibration and the secondary rows come right behind the timed sweeps -- BEFORE the profiled pass and the
+    # rocprofv3 PMC sub-runs of the roofline block (a row measured in the seconds after those sub-runs has come out 25 %
+    # slow on one box: batch 1 1.81 ms in the line, 1.43 ms in every other process of the same call)
+    calib = rows = None
+    if rank == 0 and world == 1 and not args.no_rows:
+        calib = box_calibration(device)
+        if BATCH_PER_GPU == 8:
+            rows = extra_rows(device)
     roof = None
     if rank == 0 and not args.no_roofline:
         # second, instrumented pass: HIP events around every launch of the dominant kernel
@@ -587,11 +595,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
         dist.barrier()
 
-    calib = rows = None
-    if rank == 0 and world == 1 and not args.no_rows:
-        calib = box_calibration(device)
-        if BATCH_PER_GPU == 8:
-            rows = extra_rows(device)
+    if calib is not None:
         if roof is not None and K.CONV_PRECISION == "f16x2":
             roof["frac_of_box_ceiling"] = round(roof["achieved"] / calib["three_product_ceiling_tflops"], 4)
             roof["box_ceiling_note"] = ("achieved / (this box's bare-MFMA rate on random operands / 3 products): the "

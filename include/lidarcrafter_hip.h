@@ -291,6 +291,15 @@ int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_stats* s0, 
  * ------------------------------------------------------------------------------------------- */
 int lc_resample2x_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H,
                       int W, int dir, lc_stream_t s);
+/* Round 6: a resampling ResBlock of the layout model (layout_unet_v1.py:81-150: h = op(SiLU(GroupNorm(x))), x = op(x)) in ONE
+ * pass over x.  lc_groupnorm_coeffs_os: the rows (mu, A, Bc, 0) [B][Cpad] of lc_groupnorm_coeffs, derived from the producer's
+ * statistics entries (no statistics pass); lc_resample2x_pair_fwd: y = resample(x) (bit-identical to lc_resample2x_fwd) and
+ * y_act = resample(SiLU((x - mu) * A + Bc)). */
+int lc_groupnorm_coeffs_os(const lc_oct_stats* s0, const lc_oct_stats* s1, const float* gamma, const float* beta,
+                           const float* scale, const float* shift, int64_t ss_bs, float* coeffs, int B, int C, int Cpad,
+                           int G, float eps, lc_stream_t s);
+int lc_resample2x_pair_fwd(const float* x, int64_t x_bs, const float* coeffs, int Cpad, float* y, int64_t y_bs,
+                           float* y_act, int64_t ya_bs, int B, int C, int H, int W, int dir, lc_stream_t s);
 /* Down-sampling that also leaves GroupNorm statistics of its OUTPUT (round 5): one entry per (sample, channel, slot) in
  * the producer-statistics format with unit = 1 -- ostats[B, C, slots, 4], slots = lc_resample2x_stats_slots(H, W, -1)
  * (0: the shape takes the scalar kernel, which leaves none; lc_resample2x_stats_fwd then returns LC_EUNSUP).  The

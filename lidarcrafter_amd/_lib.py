@@ -98,6 +98,8 @@ SIGNATURES = {
     "lc_attention_f16x2_fwd": (i32, [_op, _op, _op, _op, _op, _op, _op, _op, vp, i64, i64, i64,
                                      i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "lc_conv1x1_f16x2_ps_qkv_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "lc_groupnorm_coeffs_os": (i32, [_os, _os, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp]),
+    "lc_resample2x_pair_fwd": (i32, [vp, i64, vp, i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
     "lc_attention_units_elems": (i64, [i32, i32, i32, i32]),
     "lc_attention_pack_units": (i32, [_op, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lc_attention_units_fwd": (i32, [_op, _op, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),

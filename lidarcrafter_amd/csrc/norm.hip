@@ -758,6 +758,72 @@ extern "C" int lc_groupnorm_apply_os(const float* x, int64_t x_bs, const lc_oct_
     return lc_launch_status();
 }
 
+// Per-(sample, channel) rows (mu, A, Bc, 0) from the PRODUCER's statistics entries -- what gn_coeffs_kernel derives from the
+// partials of a statistics pass: y = (x - mu) * A + Bc.  One block per (group, sample): the fold of gn_apply_os_kernel, then
+// one row per channel of the group.  Consumer (round 6): the paired resampler of a resampling ResBlock (resample.hip).
+__global__ __launch_bounds__(256) void gn_coeffs_os_kernel(OctStats2 os, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, long long ss_bs,
+                                                          f32x4* __restrict__ out, int C, int Cpad, int G, float eps) {
+    __shared__ double sh[12];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, cg0 = g * cpg;
+    const bool seg1 = cg0 >= os.c0;
+    const int slots = seg1 ? os.slots1 : os.slots0;
+    const int ush = seg1 ? os.ush1 : os.ush0;
+    const f32x4* e = seg1 ? os.p1 + ((long long)b * (os.c1 >> ush) + ((cg0 - os.c0) >> ush)) * slots
+                          : os.p0 + ((long long)b * (os.c0 >> ush) + (cg0 >> ush)) * slots;
+    const int n_ent = (cpg >> ush) * slots;
+    const double P0 = (double)e[0].x;
+    double N = 0.0, S = 0.0, Q = 0.0;
+    for (int base = threadIdx.x; base < n_ent; base += 256 * 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = base + 256 * k < n_ent ? e[base + 256 * k] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double n = v[k].y, d = (double)v[k].x - P0, s_ = v[k].z;
+            N += n;
+            S += s_ + n * d;
+            Q += (double)v[k].w + d * (2.0 * s_ + n * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        N += __shfl_xor(N, o, 64); S += __shfl_xor(S, o, 64); Q += __shfl_xor(Q, o, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[3 * wv] = N; sh[3 * wv + 1] = S; sh[3 * wv + 2] = Q; }
+    __syncthreads();
+    N = (sh[0] + sh[3]) + (sh[6] + sh[9]);
+    S = (sh[1] + sh[4]) + (sh[7] + sh[10]);
+    Q = (sh[2] + sh[5]) + (sh[8] + sh[11]);
+    const double m = N > 0.0 ? S / N : 0.0;
+    double var = N > 0.0 ? Q / N - m * m : 0.0;
+    if (var < 0.0) var = 0.0;
+    const float mu = (float)(P0 + m);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int k = threadIdx.x; k < cpg; k += 256) {
+        const int c = cg0 + k;
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        const float sc = scale ? 1.0f + scale[b * ss_bs + c] : 1.0f;
+        const float sf = shift ? shift[b * ss_bs + c] : 0.0f;
+        out[(long long)b * Cpad + c] = f32x4{mu, rstd * ga * sc, be * sc + sf, 0.f};
+    }
+}
+
+extern "C" int lc_groupnorm_coeffs_os(const lc_oct_stats* s0, const lc_oct_stats* s1, const float* gamma, const float* beta,
+                                      const float* scale, const float* shift, int64_t ss_bs, float* coeffs, int B, int C,
+                                      int Cpad, int G, float eps, lc_stream_t s) {
+    if (!coeffs || B <= 0 || G <= 0 || C % G || Cpad < C) return LC_EINVAL;
+    OctStats2 os;
+    if (const int rc = os_from_segments(s0, s1, C, C / G, os)) return rc;
+    hipLaunchKernelGGL(gn_coeffs_os_kernel, dim3(G, B), dim3(256), 0, lc_s(s), os, gamma, beta, scale, shift,
+                       (long long)ss_bs, reinterpret_cast<f32x4*>(coeffs), C, Cpad, G, eps);
+    return lc_launch_status();
+}
+
 // ---- pre-split output (see gn_apply_split_kernel) -------------------------------------------------
 // (round 5 sweep of the pixels per block, 256 ... 4096, on the C2 shapes: the choices below are within 1 us of the best
 //  everywhere -- profiles/r05_second_half_raw.txt)

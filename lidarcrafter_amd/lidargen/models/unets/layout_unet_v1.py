@@ -107,8 +107,12 @@ class ResBlock(TimestepBlock):
         fuse = K.fuse_gn(self.out_channels)
         su = _stats_unit(self.out_channels)
         if self.updown:      # GN -> SiLU -> resample -> conv: the norm cannot ride on the conv
-            a = self.op(self.in_layers[0](x, act_silu=True))
-            x = self.op(x)
+            if K.RESAMPLE_PAIR and x.is_cuda and x.dtype == th.float32:
+                n0 = self.in_layers[0]       # one pass over x for both resampled tensors
+                a, x = K.groupnorm_resample_pair(x, n0.num_groups, n0.eps, n0.weight, n0.bias, up=self.op.up == 2)
+            else:
+                a = self.op(self.in_layers[0](x, act_silu=True))
+                x = self.op(x)
             h = self.in_layers[2](a, emit_stats=su)
         elif fuse:
             a = None

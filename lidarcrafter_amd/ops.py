@@ -1420,6 +1420,41 @@ def resample2x(x: torch.Tensor, up: bool, out: Optional[torch.Tensor] = None) ->
     return out
 
 
+# A resampling ResBlock of the layout model needs op(SiLU(GroupNorm(x))) AND op(x): one pass over x instead of three
+# (GroupNorm apply, resample of its result, resample of x).  LC_RESAMPLE_PAIR=0: the three passes.
+RESAMPLE_PAIR = _os.environ.get("LC_RESAMPLE_PAIR", "1") != "0"
+
+
+def groupnorm_resample_pair(x: torch.Tensor, G: int, eps: float, gamma, beta, up: bool):
+    """-> (resample2x(silu(groupnorm(x))), resample2x(x)).  The second is bit-identical to `resample2x(x, up)`; the first
+    applies the normalisation in its per-channel affine form (mu, A, Bc) while filtering."""
+    x_bs = _bs4(x, "x")
+    B, C, H, W = x.shape
+    if C % G:
+        raise ValueError(f"groupnorm: C={C} not divisible by G={G}")
+    cpad = (C + 15) // 16 * 16
+    hs = _find_stats(x, G)
+    st = _stream()
+    if hs is not None:
+        import ctypes as C_
+        from ._lib import OctStats
+
+        coef = torch.empty((B, cpad, 4), device=x.device, dtype=_F32)
+        keep = [OctStats(h.buf.data_ptr(), h.channels, h.slots, h.unit) for h in hs]
+        check(lib().lc_groupnorm_coeffs_os(C_.byref(keep[0]), C_.byref(keep[1]) if len(keep) > 1 else None, _p(gamma),
+                                           _p(beta), None, None, 0, coef.data_ptr(), B, C, cpad, G, float(eps), st),
+              "lc_groupnorm_coeffs_os")
+    else:
+        coef = groupnorm_coeffs(x, G, eps, gamma, beta)
+    shape = (B, C, 2 * H, 2 * W) if up else (B, C, H // 2, W // 2)
+    y = torch.empty(shape, device=x.device, dtype=_F32)
+    ya = torch.empty(shape, device=x.device, dtype=_F32)
+    with _Timed("resample", 4.0 * B * C * H * W * (9.0 if up else 1.5)):
+        check(lib().lc_resample2x_pair_fwd(x.data_ptr(), x_bs, coef.data_ptr(), cpad, y.data_ptr(), _bs4(y, "y"), ya.data_ptr(),
+                                           _bs4(ya, "ya"), B, C, H, W, 1 if up else -1, st), "lc_resample2x_pair_fwd")
+    return ya, y
+
+
 # ------------------------------------------------------------------------------------ dense
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None,
            act_in: bool = False, act_out: bool = False) -> torch.Tensor:

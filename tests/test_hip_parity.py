@@ -660,6 +660,29 @@ def test_attention_two_segments_and_spike(dev, prec, B, heads, L1):
     assert rel_l2(o, ref) < ATTN_TOL[prec], rel_l2(o, ref)
 
 
+@pytest.mark.parametrize("up", [False, True])
+@pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 16, 512, 8), (2, 64, 8, 64, 8), (1, 256, 4, 256, 32)])
+@pytest.mark.parametrize("producer_stats", [True, False])
+def test_groupnorm_resample_pair(dev, up, B, C, H, W, G, producer_stats):
+    """op(SiLU(GroupNorm(x))) and op(x) of a resampling ResBlock (layout_unet_v1.py:81-150) in one pass over x
+    (lc_groupnorm_coeffs_os + lc_resample2x_pair_fwd) against GroupNorm apply + two resampling passes."""
+    from lidarcrafter_amd import ops as K
+
+    src = seeded_randn(B, 32, H, W, seed=81).to(dev)
+    w = seeded_randn(C, 32, 3, 3, seed=82).to(dev) / 17.0
+    x = K.conv2d_ring(src, K.PackedConv(), w, None, emit_stats=True)        # octet entries: groups of 8 channels
+    if not producer_stats:
+        x = x.clone()                                   # carries no entries: the coefficient rows come from a statistics pass
+    assert (K._find_stats(x, G) is not None) == producer_stats
+    ga, be = seeded_randn(C, seed=83).to(dev), seeded_randn(C, seed=84).to(dev)
+    want_a = K.resample2x(K.groupnorm(x, G, 1e-5, ga, be, act_silu=True), up)
+    want_x = K.resample2x(x, up)
+    a, xr = K.groupnorm_resample_pair(x, G, 1e-5, ga, be, up)
+    assert torch.equal(xr, want_x)
+    assert rel_l2(a, want_a) < 1e-6, rel_l2(a, want_a)
+    assert float((a - want_a).abs().max()) < 2e-5 * max(1.0, float(want_a.abs().max()))
+
+
 @pytest.mark.parametrize("B,heads,Lq,Lk0,Lk1,dqk,dpos,dv", [
     (2, 3, 192, 192, 13, 32, 32, 32),      # ObjectAwareCrossAttention's shape in small: image keys ++ 13 layout keys
     (8, 8, 512, 512, 13, 32, 32, 32),      # the 8-wave block (ds 8 of the layout model)
