@@ -32,7 +32,8 @@ extern "C" {
 
 typedef void* lc_stream_t;
 
-/* Library / device probe.  Returns the ABI version (this header = 3: round 6 -- lc_conv2d_ring_f16x2_ps_fwd carries
+/* Library / device probe.  Returns the ABI version (this header = 5: the up-path fold's entry points, lc_up2_combine9_fwd / lc_split_act_fwd; 4: the
+ * unit-form attention; 3: round 6 -- lc_conv2d_ring_f16x2_ps_fwd carries
  * gn_ostats_unit, the stride-2 / calibration entry points exist; 2: round 3 -- field-of-view arguments are doubles,
  * lc_layout_condition takes float32 or float64 boxes, float64 point sets).  Bumped whenever an exported signature
  * changes; lidarcrafter_amd/_lib.py refuses a library of another version. */
@@ -307,6 +308,24 @@ int lc_resample2x_pair_fwd(const float* x, int64_t x_bs, const float* coeffs, in
 int64_t lc_resample2x_stats_slots(int H, int W, int dir);
 int lc_resample2x_stats_fwd(const float* x, int64_t x_bs, float* y, int64_t y_bs, int B, int C, int H,
                             int W, int dir, float* ostats, lc_stream_t s);
+
+/* Round 6 (third part): Conv2d(3x3, ring) BEHIND Resample(up=2) folded -- layout_unet_v1.py:219-235 (ResBlock up=True:
+ * in_rest -> op(h) -> in_conv) and efficient_unet.py:143-145 (Block.upsample), ops.py:52-173.  Both operators are linear:
+ *   conv3x3(U(a))[r][s] = bias + sum_{ky,kx} U(P_{ky,kx})[r + ky - 1][s + kx - 1 (ring)],   P_{ky,kx} = W[:, :, ky, kx] . a
+ * (rows of U(.) outside [0, 2H) are the conv's zero padding).  The nine planes are ONE 1x1 projection Ci -> 9 Co of the
+ * LOW-resolution operand (lc_conv1x1_f16x2_ps_fwd with the weight rows ordered t Co + co, t = 3 ky + kx: a quarter of the
+ * 3x3 conv's multiply-adds), lc_up2_combine9_fwd reads them once and writes y [B][Co][2H][2W] once, with the bias and --
+ * ostats != NULL -- one GroupNorm statistics entry per (sample, channel, slot) of what it stores (lc_oct_stats, unit = 1,
+ * ostats[B][Co][slots][4], slots = lc_up2_combine9_stats_slots(H, W); 0: shape unsupported).  Needs W % 128 == 0, p9
+ * 8-byte and y 16-byte aligned (LC_EUNSUP otherwise).
+ * lc_split_act_fwd: the plain fp32 -> pre-split pass (x * range->x_scale as fp16 hi / lo planes in the layout of
+ * lc_groupnorm_apply_split, lc_split_act_units(B, C, H, W) units; publishes max |x * x_scale|) for an operand that no
+ * GroupNorm apply pass writes; C % 16 == 0, H * W % 4 == 0, x 16-byte aligned. */
+int lc_split_act_fwd(const float* x, int64_t x_bs, void* y_split, int B, int C, int H, int W, lc_conv_range* range,
+                     lc_stream_t s);
+int64_t lc_up2_combine9_stats_slots(int H, int W);
+int lc_up2_combine9_fwd(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs, int B, int Co, int H,
+                        int W, float* ostats, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Small dense layer  y[m, n] = sum_k act(x[m,k]) * w[n,k] + b[n]   (w in nn.Linear layout).

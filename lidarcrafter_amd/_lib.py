@@ -100,6 +100,9 @@ SIGNATURES = {
     "lc_conv1x1_f16x2_ps_qkv_fwd": (i32, [vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "lc_groupnorm_coeffs_os": (i32, [_os, _os, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp]),
     "lc_resample2x_pair_fwd": (i32, [vp, i64, vp, i32, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "lc_split_act_fwd": (i32, [vp, i64, vp, i32, i32, i32, i32, vp, vp]),
+    "lc_up2_combine9_stats_slots": (i64, [i32, i32]),
+    "lc_up2_combine9_fwd": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     "lc_attention_units_elems": (i64, [i32, i32, i32, i32]),
     "lc_attention_pack_units": (i32, [_op, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lc_attention_units_fwd": (i32, [_op, _op, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
@@ -146,7 +149,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4   # include/lidarcrafter_hip.h lc_abi_version: bumped with every change of an exported signature
+ABI_VERSION = 5   # include/lidarcrafter_hip.h lc_abi_version: bumped with every change of an exported signature
 
 
 class HipLibraryMissing(RuntimeError):

@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "liblidarcrafter_hip.so")
 # the convolution kernels alone with ONE fp16 product per multiply (-DLC_F16X2_TERMS=1): what a caller under
 # torch.autocast(float16) asked for (the reference's bulk harness); never used otherwise (ops.conv_products)
 LIB_P1 = os.path.join(HERE, "liblidarcrafter_hip_p1.so")
-SOURCES = ["conv.hip", "conv_f16x2.hip", "conv_f16x2_tall.hip", "conv_f16x2_s2.hip", "norm.hip", "resample.hip", "misc.hip", "attention.hip", "attention_units.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip", "conv_bwd.hip", "attention_bwd.hip", "attention_bwd_h.hip"]
+SOURCES = ["conv.hip", "conv_f16x2.hip", "conv_f16x2_tall.hip", "conv_f16x2_s2.hip", "norm.hip", "resample.hip", "upfold.hip", "misc.hip", "attention.hip", "attention_units.hip", "geometry.hip", "roipool.hip", "lidar.hip", "layout.hip", "temporal.hip", "metrics.hip", "voxel.hip", "conv_bwd.hip", "attention_bwd.hip", "attention_bwd_h.hip"]
 
 
 def hipcc() -> str:

@@ -22,14 +22,20 @@ namespace {
 // BPV = pixels per block: 256 (8 waves, 2 x 48 KB of LDS: one block per CU) or 128 (4 waves, 2 x 32 KB: two blocks per CU --
 // the shapes whose 256-pixel grid leaves CUs idle or runs a half-empty second round, e.g. 512 -> 1536 @ 4 x 128 at batch 8:
 // 192 blocks on 256 CUs)
-template <int BPV>
+// BNV / MIV (round 6, third part): output channels per block and 32-channel accumulator rows per wave.  128 / 2 = the form
+// above.  288 / 3 (6 waves of 96 channels x 64 pixels, 128-pixel blocks, 2 x 52 KB of LDS): the projection to the NINE tap
+// planes of the up-path fold (csrc/upfold.hip: Co' = 9 Co, a multiple of 288 for every Co % 32 == 0) -- 9 Co x pixels
+// then divides into blocks whose number is a multiple of the chip's 256 CUs at every shape of the denoisers (2304 x 4096:
+// 256 blocks, where the 128 x 256 grid had 288 = 1.125 rounds), and a wave issues 36 MFMAs between two barriers instead of 24.
+template <int BPV, int BNV = 128, int MIV = 2>
 struct P1T {
-    static constexpr int BN = 128, BP = BPV, CBK = 4, NWV = 2 * (BPV / 64), NT = 64 * NWV;
+    static constexpr int BN = BNV, BP = BPV, CBK = 4, MI = MIV, NWV = (BNV / (32 * MIV)) * (BPV / 64), NT = 64 * NWV;
     static constexpr int XS = CBK * BP, WS = CBK * BN;            // units per plane per buffer
-    static constexpr int BUF = 2 * XS + 2 * WS;                   // 48 KB / 32 KB
-    static constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk: 32 + 16 / 16 + 16
-    static constexpr int IPW = (NX + NW) / NWV;                   // per wave: 6 / 8
-    static_assert(NX % NWV == 0 && NW % NWV == 0, "the kind of a DMA slot must not depend on the wave");
+    static constexpr int BUF = 2 * XS + 2 * WS;                   // 48 KB / 32 KB / 52 KB
+    static constexpr int NX = 2 * XS / 64, NW = 2 * WS / 64;      // DMA wave-instructions per chunk: 32 + 16 / 16 + 16 / 16 + 36
+    static constexpr int XPW = (NX + NWV - 1) / NWV;              // x slots per wave (the last may be absent: NX % NWV != 0)
+    static constexpr int IPW = XPW + NW / NWV;                    // per wave: 6 / 8 / 9
+    static_assert(BNV % (32 * MIV) == 0 && NW % NWV == 0 && WS % 64 == 0 && XS % 64 == 0, "the kind of a DMA slot must not depend on the wave");
 };
 using P1 = P1T<256>;
 
@@ -44,6 +50,13 @@ struct P1Args {
     // the keys and values of ObjectAwareCrossAttention, 32 channels per head -- go straight into the unit form the
     // attention kernel stages by LDS-DMA (csrc/attention_units.hip; kv: [B][heads][kv_tiles][768] units of 8 halves)
     half8* kv; int C, kv_heads, kv_tiles;
+    // store form of the plain epilogue: 0 = one write-through dword per lane and register (two 128-byte runs per wave
+    // instruction); 2 = each 32 x 32 accumulator tile transposed through the wave's own LDS strip and stored as 16 bytes per
+    // lane (eight 128-byte rows per wave instruction), write-through -- measured on the nine-plane projections of the
+    // up-path fold (output-heavy: 9 Co channels from one pass over K): 47 -> 23 us at 256 -> 2304 @ 8 x 4 x 128, 100 -> 68 at
+    // 512 -> 4608, 184 -> 108 at 128 -> 1152 @ 8 x 16 x 512 (profiles/r06_fold_up.txt); write-back instead of write-through
+    // changes neither form.  Form 2 needs P % 4 == 0, a 16-byte aligned y and no residual (the launcher falls back to 0).
+    int st_mode;
 };
 
 // The 8-byte halves of a K unit / the 16-byte V units a lane of the QKV epilogue owns; the split is the attention kernels'
@@ -59,12 +72,13 @@ __device__ __forceinline__ void qkv_split2(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
 }
 
-template <bool QKV, int BPV = 256>
-__global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_kernel(P1Args a) {
-    using P1 = P1T<BPV>;
-    constexpr int BN = P1::BN, BP = P1::BP, CBK = P1::CBK, XS = P1::XS, WS = P1::WS, BUF = P1::BUF;
-    constexpr int NX = P1::NX, NW = P1::NW, IPW = P1::IPW, NWV = P1::NWV, WPX = BP / 64;
+template <bool QKV, int BPV = 256, int BNV = 128, int MIV = 2>
+__global__ __launch_bounds__((P1T<BPV, BNV, MIV>::NT), (BPV == 256 || BNV != 128 ? 1 : 2)) void conv1x1_ps_kernel(P1Args a) {
+    using P1 = P1T<BPV, BNV, MIV>;
+    constexpr int BN = P1::BN, BP = P1::BP, CBK = P1::CBK, XS = P1::XS, WS = P1::WS, BUF = P1::BUF, MI = P1::MI, WCO = 32 * MI;
+    constexpr int NX = P1::NX, NW = P1::NW, IPW = P1::IPW, NWV = P1::NWV, WPX = BP / 64, XPW = P1::XPW;
     constexpr unsigned OOB = 0x80000000u;
+    static_assert(!QKV || (BNV == 128 && MIV == 2), "the QKV epilogue is written for the 128 x 2 form");
     __shared__ half8 lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,19 +98,22 @@ __global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_k
     int ldsoff[IPW];
 #pragma unroll
     for (int k = 0; k < IPW; ++k) {
-        const int j = wave + NWV * k;
-        if (k < NX / NWV) {
+        if (k < XPW) {
+            const int j = wave + NWV * k;
             const int plane = j / (NX / 2), rem = j - plane * (NX / 2);
             const int cb = rem / (BP / 64), q = rem - cb * (BP / 64);
             const int p = p0 + q * 64 + lane;
-            ldsoff[k] = plane * XS + cb * BP + q * 64;
-            voff[k] = p < a.P ? (unsigned)((plane * a.C8 + cb) * a.P + p) * 16u : OOB;
+            const bool slot = j < NX;                          // (wave-uniform; false only where NX % NWV != 0)
+            ldsoff[k] = slot ? plane * XS + cb * BP + q * 64 : 0;
+            voff[k] = slot && p < a.P ? (unsigned)((plane * a.C8 + cb) * a.P + p) * 16u : OOB;
         } else {
-            const int jw = j - NX;
-            const int plane = jw / (NW / 2), rem = jw - plane * (NW / 2);
-            const int cb = rem / (BN / 64), q = rem - cb * (BN / 64);
-            const int cu = co0 + q * 64 + lane;
-            ldsoff[k] = 2 * XS + plane * WS + cb * BN + q * 64;
+            // (a plane's image [cb 4][BN] is one run of WS units: a wave-instruction moves 64 consecutive ones, which may
+            //  straddle two channel blocks when BN % 64 != 0 -- the source offset is per lane anyway)
+            const int jw = wave + NWV * (k - XPW);
+            const int plane = jw / (NW / 2), q = jw - plane * (NW / 2);
+            const int u = q * 64 + lane;
+            const int cb = u / BN, cu = co0 + (u - cb * BN);
+            ldsoff[k] = 2 * XS + plane * WS + q * 64;
             voff[k] = cu < a.Cop ? ((unsigned)(cb * a.Cop + cu) + plane * wplane) * 16u : OOB;
         }
     }
@@ -104,14 +121,21 @@ __global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_k
     const unsigned w_chunk = (unsigned)CBK * (unsigned)a.Cop * 16u;    // ... (weights)
     auto issue = [&](half8* buf, int ch) {
 #pragma unroll
-        for (int k = 0; k < IPW; ++k)
-            if (k < NX / NWV) lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
-            else lds_dma16(rs_w, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * w_chunk);
+        for (int k = 0; k < IPW; ++k) {
+            if (k < XPW) {
+                // (the last x slot of a wave does not exist where NX % NWV != 0: a wave-uniform branch, and every wait
+                //  of this kernel is vmcnt(0))
+                if (NX % NWV == 0 || k + 1 < XPW || wave + NWV * k < NX)
+                    lds_dma16(rs_x, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * x_chunk);
+            } else {
+                lds_dma16(rs_w, (lds_vptr)(buf + ldsoff[k]), voff[k], (unsigned)ch * w_chunk);
+            }
+        }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -138,11 +162,11 @@ __global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_k
             const half8* wl = wh + WS;
 #pragma unroll
             for (int ks = 0; ks < CBK / 2; ++ks) {
-                half8 ah[2], al[2], bh[2], bl[2];
+                half8 ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ah[i] = wh[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
-                    al[i] = wl[(2 * ks + kh) * BN + wco * 64 + i * 32 + l31];
+                for (int i = 0; i < MI; ++i) {
+                    ah[i] = wh[(2 * ks + kh) * BN + wco * WCO + i * 32 + l31];
+                    al[i] = wl[(2 * ks + kh) * BN + wco * WCO + i * 32 + l31];
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_k
                     bl[j] = xl[(2 * ks + kh) * BP + wpx * 64 + j * 32 + l31];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if (VT) {
@@ -176,15 +200,15 @@ __global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_k
     const float out_unscale = a.range->x_unscale * a.wmeta[1];
     float* yb = a.y + (long long)b * a.y_bs;
     const float* rb = a.res ? a.res + (long long)b * a.res_bs : nullptr;
-    const int co_lane = co0 + wco * 64 + 4 * kh;
-    float bias_r[2][16];
+    const int co_lane = co0 + wco * WCO + 4 * kh;
+    float bias_r[MI][16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
             // (QKV value blocks: the accumulators are transposed, a lane owns ONE channel per 32-block)
-            const int cb_ = (QKV && vt) ? co0 + wco * 64 + i * 32 + l31 : co;
+            const int cb_ = (QKV && vt) ? co0 + wco * WCO + i * 32 + l31 : co;
             bias_r[i][r] = (a.bias && cb_ < a.Co) ? a.bias[cb_] : 0.0f;
         }
     if (QKV && co0 >= a.C) {
@@ -234,20 +258,46 @@ __global__ __launch_bounds__(P1T<BPV>::NT, BPV == 256 ? 1 : 2) void conv1x1_ps_k
         }
         return;
     }
+    if (a.st_mode >= 2 && !rb) {
+        // (behind the K loop's last barrier: the operand buffers are free.  A strip = 32 rows x 36 floats, rows 16-byte
+        //  aligned; the wave writes its tile in the accumulator layout and reads it back as rows -- LDS operations of one
+        //  wave execute in order, the wave barriers only keep the compiler from moving them across each other)
+        float* strip = reinterpret_cast<float*>(lds) + wave * (32 * 36);
+        const __amdgpu_buffer_rsrc_t rs_yb = __builtin_amdgcn_make_buffer_rsrc(yb, 0, 0x7FFFFFFFu, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    strip[((r & 3) + 8 * (r >> 2) + 4 * kh) * 36 + l31] = (acc[i][j][r] * out_unscale + bias_r[i][r]) * a.out_scale;
+                __builtin_amdgcn_wave_barrier();
+                const int cob = co0 + wco * WCO + i * 32, pb_ = p0 + wpx * 64 + j * 32 + 4 * (lane & 7);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * 36 + 4 * (lane & 7));
+                    const unsigned off = cob + row < a.Co && pb_ < a.P ? ((unsigned)(cob + row) * (unsigned)a.P + (unsigned)pb_) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lc_u32x4, v), rs_yb, off, 0, 16);   // sc1
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int p = p0 + wpx * 64 + j * 32 + l31;
         const bool pok = p < a.P;
-        float res_r[2][16];                                 // all residual loads of this pixel column in flight together
+        float res_r[MI][16];                                // all residual loads of this pixel column in flight together
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
                 res_r[i][r] = (rb && pok && co < a.Co) ? rb[(long long)co * a.P + p] : 0.0f;
             }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_lane + i * 32 + (r & 3) + 8 * (r >> 2);
@@ -270,6 +320,22 @@ static bool p1_small_tile(int B, long long P, int Co) {
     return blocks256 <= 256;      // (384 blocks -- 256 -> 768 @ 8 x 256 at batch 8 -- measure 42 against 46.5 us inside a step)
 }
 
+// 288-channel blocks when the output channels divide into them (9 Co' of the up-path fold) and the grid is at most two rounds
+// of the chip (256 / 512 blocks where the 128-channel forms run 1.125 / 2.25 rounds: 30.5 -> 22.8 us at 256 -> 2304 @ 8 x 4 x 128,
+// 75.4 -> 67.7 at 512 -> 4608; on longer grids the 128-channel forms are ahead: 78.9 against 84.9 us at 256 -> 2304 @ 8 x 8 x 256);
+// LC_P1_BN=128 / 288 forces one
+static bool p1_wide_tile(int B, long long P, int Co) {
+    static const int env = [] { const char* e = getenv("LC_P1_BN"); return e ? atoi(e) : 0; }();
+    if (Co % 288 || env == 128) return false;
+    return env == 288 || (long long)B * ((P + 127) / 128) * (Co / 288) <= 512;
+}
+
+// LC_P1_ST=0: the dword form of the plain epilogue everywhere (developer A/B)
+static int p1_store_mode() {
+    static const int env = [] { const char* e = getenv("LC_P1_ST"); return e ? atoi(e) : 2; }();
+    return env;
+}
+
 // x_split: [B][2][Ci/8][P][8] halves as lc_groupnorm_apply*_split write them (P = H * W); wp_hi / wp_lo / wmeta: the ks = 1
 // pack of lc_pack_conv_weight_f16x2 (lo plane directly behind the hi plane); y, res: fp32 [B][Co][P] with batch strides.
 extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, const void* wp_lo, const float* bias,
@@ -288,6 +354,13 @@ extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, c
     a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
     a.Co = Co; a.out_scale = out_scale; a.range = range; a.wmeta = wmeta;
     a.kv = nullptr; a.C = a.kv_heads = a.kv_tiles = 0;
+    a.st_mode = (p1_store_mode() == 2 && !res && P % 4 == 0 && (y_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 2 : 0;
+    if (p1_wide_tile(B, P, Co)) {       // 288 x 128 blocks (the nine tap planes of the up-path fold: Co = 9 Co')
+        using PW = P1T<128, 288, 3>;
+        dim3 grid((unsigned)(B * ((P + 127) / 128)), (unsigned)(Co / PW::BN));
+        hipLaunchKernelGGL((conv1x1_ps_kernel<false, 128, 288, 3>), grid, dim3(PW::NT), 0, lc_s(s), a);
+        return lc_launch_status();
+    }
     if (p1_small_tile(B, P, Co)) {
         dim3 grid((unsigned)(B * ((P + 127) / 128)), (unsigned)((Co + P1::BN - 1) / P1::BN));
         hipLaunchKernelGGL((conv1x1_ps_kernel<false, 128>), grid, dim3(P1T<128>::NT), 0, lc_s(s), a);
@@ -318,6 +391,7 @@ extern "C" int lc_conv1x1_f16x2_ps_qkv_fwd(const void* x_split, const void* wp_h
     a.bias = bias; a.res = nullptr; a.res_bs = 0; a.y = q; a.y_bs = q_bs;
     a.Co = Co; a.out_scale = 1.0f; a.range = range; a.wmeta = wmeta;
     a.kv = (half8*)kv; a.C = C; a.kv_heads = C / 32; a.kv_tiles = (int)(P / 32) + (Lk1 > 0);
+    a.st_mode = (p1_store_mode() == 2 && (q_bs & 3) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0) ? 2 : 0;   // (P % 32 == 0 here)
     if (p1_small_tile(B, P, Co)) {
         dim3 grid((unsigned)(B * ((P + 127) / 128)), (unsigned)(Co / P1::BN));
         hipLaunchKernelGGL((conv1x1_ps_kernel<true, 128>), grid, dim3(P1T<128>::NT), 0, lc_s(s), a);

@@ -194,7 +194,7 @@ inline int grid_for(long long n) {
 
 }  // namespace
 
-extern "C" int lc_abi_version(void) { return 4; }
+extern "C" int lc_abi_version(void) { return 5; }
 
 extern "C" int64_t lc_calibrate_mfma_f16(const void* operands, int blocks, int iters, float* sink, lc_stream_t s) {
     if (!operands || !sink || blocks <= 0 || iters <= 0) return LC_EINVAL;
@@ -231,10 +231,11 @@ int lc_touch_norm();
 int lc_touch_resample();
 int lc_touch_roipool();
 int lc_touch_temporal();
+int lc_touch_upfold();
 int lc_touch_voxel();
 }
 extern "C" int lc_load_code_objects(void) {
-    int (*const touch[])() = {lc_touch_attention, lc_touch_attention_bwd, lc_touch_attention_bwd_h, lc_touch_conv, lc_touch_conv_bwd, lc_touch_conv_f16x2, lc_touch_conv_f16x2_tall, lc_touch_conv_f16x2_s2, lc_touch_geometry, lc_touch_layout, lc_touch_lidar, lc_touch_metrics, lc_touch_norm, lc_touch_resample, lc_touch_roipool, lc_touch_temporal, lc_touch_voxel};
+    int (*const touch[])() = {lc_touch_attention, lc_touch_attention_bwd, lc_touch_attention_bwd_h, lc_touch_conv, lc_touch_conv_bwd, lc_touch_conv_f16x2, lc_touch_conv_f16x2_tall, lc_touch_conv_f16x2_s2, lc_touch_geometry, lc_touch_layout, lc_touch_lidar, lc_touch_metrics, lc_touch_norm, lc_touch_resample, lc_touch_roipool, lc_touch_temporal, lc_touch_upfold, lc_touch_voxel};
     for (auto f : touch) {
         const int rc = f();
         if (rc != 0) return rc;

@@ -143,6 +143,8 @@ class Block(nn.Module):
         self.upsample = (nn.Sequential(ops.Resample(up=up, ring=ring),
                                        ops.Conv2d(out_channels, out_channels, 3, 1, 1, ring=ring))
                          if up > 1 else nn.Identity())
+        self._packed_up9 = K.PackedConv() if up > 1 else None     # the up-path fold's 1x1 projection (ops.conv_up2)
+        self._up9_cache = None
 
     def forward(self, h, temb=None, scale_shifts=None, out=None):
         """`out`: optional destination view for the block's final tensor (concat-buffer slice).
@@ -169,8 +171,29 @@ class Block(nn.Module):
         if has_attn:
             h = self.self_attn_block(h, out=out if not has_up else None)
         if has_up:   # feeds the next block's first GroupNorm (through the concat buffer)
-            h = self.upsample[1](self.upsample[0](h), out=out, emit_stats=True)
+            rs, conv = self.upsample
+            B_, C_, H_, W_ = h.shape
+            if rs.up == 2 and conv.ring and h.is_cuda and h.dtype == torch.float32 and h.data_ptr() % 16 == 0 \
+                    and (H_ * W_) % 4 == 0 and K.can_fold_up(C_, conv.out_channels, H_, W_):
+                # conv3x3(up(h)) at the LOW resolution: h pre-split as it is, one 1x1 projection to the nine tap planes (a
+                # quarter of the multiply-adds), the combine pass (ops.conv_up2, csrc/upfold.hip); per-channel statistics
+                xs = K.split_act(h, self._packed_up9)
+                h = K.conv_up2(xs, self._packed_up9, self._up9_weight(), conv.bias, out=out, emit_stats=True)
+            else:
+                h = conv(rs(h), out=out, emit_stats=True)
         return h
+
+    def _up9_weight(self):
+        """ops.up9_weight(upsample conv weight), rebuilt when the parameter changes (address / version)."""
+        w = self.upsample[1].weight
+        try:
+            ver = w._version
+        except RuntimeError:      # inference-mode tensors do not track one
+            ver = -1
+        key = (w.data_ptr(), ver, w.device)
+        if self._up9_cache is None or self._up9_cache[0] != key:
+            self._up9_cache = (key, K.up9_weight(w))
+        return self._up9_cache[1]
 
 
 class EfficientUNet(nn.Module):

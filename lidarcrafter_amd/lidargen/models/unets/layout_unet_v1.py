@@ -78,6 +78,9 @@ class ResBlock(TimestepBlock):
             normalization(channels), SiLU(),
             conv_nd_range(dims, channels, self.out_channels, 3, padding=1, ring=True))
         self.updown = up or down
+        self._packed_up9 = K.PackedConv() if up else None      # the fold's 1x1 projection (ops.conv_up2)
+        self._up9_cache = None
+        self.fold_up_off = False
         if up:
             self.op = ops.Resample(up=2, ring=True)
         elif down:
@@ -102,11 +105,39 @@ class ResBlock(TimestepBlock):
         C = self.out_channels
         return ss[:, :C], ss[:, C:]
 
+    # ---- up-sampling ResBlock folded (round 6): in_conv(op(act(norm(x)))) at the low resolution ------------------------
+    def _up9_weight(self):
+        """ops.up9_weight(in_conv.weight), rebuilt when the parameter changes (address / version)."""
+        w = self.in_layers[2].weight
+        key = (w.data_ptr(), _ver(w), w.device)
+        if self._up9_cache is None or self._up9_cache[0] != key:
+            self._up9_cache = (key, K.up9_weight(w))
+        return self._up9_cache[1]
+
+    def _fold_up_operand(self, x):
+        """SiLU(GroupNorm(x)) pre-split for the fold's 1x1 projection, or None where the fold does not apply."""
+        if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 4):
+            return None
+        B, C, H, W = x.shape
+        if not K.can_fold_up(C, self.out_channels, H, W) or self.fold_up_off:
+            return None
+        a = self.in_layers[0](x, act_silu=True, split_for=self._packed_up9)
+        return a if isinstance(a, K.SplitAct) else None
+
     def forward(self, x, emb=None, scale_shift=None, out=None):
         scale, shift = scale_shift if scale_shift is not None else self.scale_shift(emb)
         fuse = K.fuse_gn(self.out_channels)
         su = _stats_unit(self.out_channels)
         if self.updown:      # GN -> SiLU -> resample -> conv: the norm cannot ride on the conv
+            a = self._fold_up_operand(x) if self._packed_up9 is not None else None
+            if a is not None:
+                # conv3x3(up(a)) computed at the LOW resolution: one 1x1 projection to the nine tap planes (a quarter of the
+                # multiply-adds) + the combine pass (ops.conv_up2, csrc/upfold.hip); it leaves per-channel statistics entries
+                h = K.conv_up2(a, self._packed_up9, self._up9_weight(), self.in_layers[2].bias, emit_stats=True)
+                x = self.op(x)
+                a2 = self.out_layers[0](h, scale, shift, act_silu=True, split_for=self.out_layers[3]._packed)
+                sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
+                return self.out_layers[3](a2, res=sk, out=out, emit_stats=su)
             if K.RESAMPLE_PAIR and x.is_cuda and x.dtype == th.float32:
                 n0 = self.in_layers[0]       # one pass over x for both resampled tensors
                 a, x = K.groupnorm_resample_pair(x, n0.num_groups, n0.eps, n0.weight, n0.bias, up=self.op.up == 2)

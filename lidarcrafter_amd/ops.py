@@ -1179,6 +1179,90 @@ def conv_down2(x: torch.Tensor, packed: PackedConv, weight, bias, out: Optional[
     return out
 
 
+# ---- Conv2d(3x3, ring) BEHIND Resample(up=2) folded (round 6, third part; csrc/upfold.hip has the algebra): the nine tap
+# planes W[:, :, ky, kx] . a are ONE 1x1 projection Ci -> 9 Co of the LOW-resolution operand (a quarter of the 3x3 conv's
+# multiply-adds at the high resolution), lc_up2_combine9_fwd up-samples, shifts and sums them in one pass.  LC_FOLD_UP=0: the
+# reference's order (resampling pass, then the conv at the high resolution).  Below LC_FOLD_UP_MIN_CI input channels the
+# launches are bound by the bytes of the 9-plane intermediate (2.25x the conv's output), not by the matrix pipes: the order
+# of the reference stays (profiles/r06_fold_up.txt: 64 -> 64 @ 8 x 16 x 512 folded 93 us against 89).
+FOLD_UP = _os.environ.get("LC_FOLD_UP", "1") != "0"
+FOLD_UP_MIN_CI = int(_os.environ.get("LC_FOLD_UP_MIN_CI", "128"))
+
+
+def can_fold_up(Ci: int, Co: int, H: int, W: int) -> bool:
+    """(H, W) = the LOW resolution.  Needs the pre-split 1x1 kernel (Ci % 32) and whole 128-column segments."""
+    return (FOLD_UP and PRESPLIT and CONV_PRECISION == "f16x2" and Ci % 32 == 0 and Ci >= FOLD_UP_MIN_CI
+            and W % 128 == 0 and H >= 1 and 9 * Co * H * W * 4 < (1 << 31))
+
+
+def up9_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Co, Ci, 3, 3] -> the 1x1 weight [9 Co, Ci, 1, 1] of the fold: row t Co + co = W[co, :, ky, kx], t = 3 ky + kx."""
+    Co, Ci = weight.shape[:2]
+    # (outside inference mode: the samplers run under torch.inference_mode, and PackedConv keys its caches on the version
+    #  counter, which inference tensors do not carry)
+    with torch.inference_mode(False), torch.no_grad():
+        return weight.detach().permute(2, 3, 0, 1).reshape(9 * Co, Ci, 1, 1).contiguous()
+
+
+def split_act(x: torch.Tensor, packed: PackedConv) -> SplitAct:
+    """x as it is (no normalisation) in the pre-split form of `packed`'s input (lc_split_act_fwd)."""
+    x_bs = _bs4(x, "x")
+    B, C, H, W = x.shape
+    units = int(lib().lc_split_act_units(B, C, H, W))
+    buf = torch.empty((units, 8), device=x.device, dtype=torch.float16)
+    with _Timed("groupnorm", 8.0 * B * C * H * W):
+        check(lib().lc_split_act_fwd(x.data_ptr(), x_bs, buf.data_ptr(), B, C, H, W, packed.range_ptr(x.device), _stream()),
+              "lc_split_act_fwd")
+    return SplitAct(buf, (B, C, H, W), packed)
+
+
+def conv_up2(xs, packed9: PackedConv, weight9: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None, emit_stats=False) -> torch.Tensor:
+    """y = Conv2d_ring3x3(Resample(up=2)(a)) + bias of the reference for a [B, Ci, H, W] -> [B, Co, 2H, 2W], computed at the
+    LOW resolution.  xs: `a` pre-split for `packed9` (a SplitAct from `groupnorm(..., split_for=packed9)` / `split_act`),
+    weight9 = `up9_weight(conv.weight)` (the caller caches it per weight version), packed9 its PackedConv.
+    emit_stats: per-channel GroupNorm statistics entries of the result (any consumer folds them)."""
+    if not isinstance(xs, SplitAct) or xs.packed is not packed9:
+        raise ValueError("conv_up2: needs the operand pre-split for this layer (groupnorm(split_for=packed9) / split_act)")
+    B, Ci, H, W = xs.shape
+    if weight9.dim() != 4 or weight9.shape[1] != Ci or weight9.shape[0] % 9 or tuple(weight9.shape[2:]) != (1, 1):
+        raise ValueError("conv_up2: weight9 must be up9_weight(conv.weight) = [9 Co, Ci, 1, 1]")
+    Co = weight9.shape[0] // 9
+    if not can_fold_up(Ci, Co, H, W):
+        raise ValueError("conv_up2: needs Ci % 32 == 0, Ci >= LC_FOLD_UP_MIN_CI, W % 128 == 0 (ops.can_fold_up)")
+    dev = xs.buf.device
+    if out is None:
+        out = torch.empty((B, Co, 2 * H, 2 * W), device=dev, dtype=_F32)
+    y_bs = _bs4(out, "out")
+    if tuple(out.shape) != (B, Co, 2 * H, 2 * W):
+        raise ValueError(f"conv_up2: out shape {tuple(out.shape)} != {(B, Co, 2 * H, 2 * W)}")
+    if bias is not None:
+        _req(bias, "bias")
+    _drop_stats(out)
+    wh, wl = packed9.get_f16x2(weight9)
+    if packed9.ks != 1 or packed9.Ci != Ci:
+        raise ValueError("conv_up2: packed9 does not hold weight9")
+    p9 = torch.empty((B, 9 * Co, H, W), device=dev, dtype=_F32)
+    # (algorithmic work = the reference's 3x3 conv at the HIGH resolution, which this launch replaces; it executes a quarter)
+    with _Timed("conv3x3", 2.0 * B * 4 * H * W * Co * Ci * 9, executed=2.0 * B * H * W * 9 * Co * Ci,
+                rd=4.0 * (B * Ci * H * W + Co * Ci * 9), wr=4.0 * B * 9 * Co * H * W):
+        check(_conv_lib().lc_conv1x1_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(), None, None, 0,
+                                                  p9.data_ptr(), 9 * Co * H * W, B, Ci, 9 * Co, H, W, 1.0,
+                                                  packed9.wmeta.data_ptr(), packed9.range_ptr(dev), _stream()),
+              "lc_conv1x1_f16x2_ps_fwd")
+    sbuf, slots = None, 0
+    if emit_stats and PRODUCER_GN_STATS:
+        slots = int(lib().lc_up2_combine9_stats_slots(H, W))
+        if slots > 0:
+            sbuf = torch.empty((B, Co, slots, 4), device=dev, dtype=_F32)
+    with _Timed("resample", 4.0 * B * Co * H * W * 13.0):
+        check(lib().lc_up2_combine9_fwd(p9.data_ptr(), _bs4(p9, "p9"), _p(bias), out.data_ptr(), y_bs, B, Co, H, W,
+                                        _p(sbuf), _stream()), "lc_up2_combine9_fwd")
+    if sbuf is not None:
+        _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, 4 * H * W), 1))
+    return out
+
+
 # Split-K (pre-split conv): when a 3x3 conv has fewer than SPLITK_MAX_BLOCKS output tiles (batch
 # 1-2 at the deep levels), its K range is divided over several blocks per tile.
 SPLITK = _os.environ.get("LC_SPLITK", "1") != "0"

@@ -97,6 +97,23 @@ def sec_fold_down():
     save("fold_down", **out)
 
 
+def sec_fold_up():
+    """Block.upsample of the reference's EfficientUNet (efficient_unet.py:143-145) = the inner pair of LayoutUnetV1's
+    up-sampling ResBlock (layout_unet_v1.py:219-235): ops.Resample(up=2) followed by ops.Conv2d(3x3, ring) -- the pair the
+    HIP path evaluates at the LOW resolution (lidarcrafter_amd/csrc/upfold.hip: nine 1x1 tap planes + one combine pass).
+    Shapes: one and several 128-column segments, H = 1 (both H borders in one row pair), Ci != Co, an input with a mean
+    (the bias and the dropped border taps show).  Every second column is stored."""
+    ops = R.ref("models.unets.ops")
+    out = {}
+    with torch.no_grad():
+        for tag, (B, Ci, Co, H, W, salt) in {"a": (2, 32, 32, 4, 128, 41), "b": (1, 64, 40, 1, 256, 42),
+                                             "c": (1, 128, 128, 8, 128, 43), "d": (2, 32, 16, 2, 384, 44)}.items():
+            conv = seeded_fill(ops.Conv2d(Ci, Co, 3, 1, 1, ring=True), salt=salt)
+            x = seeded_randn(B, Ci, H, W, seed=400 + salt) + 0.3
+            out[f"{tag}_y"] = conv(ops.Resample(up=2, ring=True)(x))[..., ::2]
+    save("fold_up", **out)
+
+
 def _build_uncond(eu, base, res):
     m = eu.EfficientUNet(2, res, base_channels=base, temb_channels=None,
                          channel_multiplier=(1, 2, 4, 8), num_residual_blocks=(3, 3, 3, 3),

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol():
     handle = _lib.lib()
     for name in _declared():
         assert hasattr(handle, name), name
-    assert handle.lc_abi_version() == 4
+    assert handle.lc_abi_version() == 5
     # pure host-side helpers are callable without a GPU
     assert handle.lc_packed_conv_weight_elems(2, 64, 3) == 9 * 64 * 64
     assert handle.lc_packed_conv_weight_elems(100, 42, 1) == 48 * 128
