@@ -65,6 +65,10 @@ class SelfAttentionBlock(nn.Module):
         if K.fuse_gn(3 * C):
             qkv = K.conv2d_ring(x, self._pk_in, w_in, self.attn.in_proj_bias,
                                 gn_coeffs=self.norm.coeffs(x), gn_silu=False)
+        elif K.presplit_1x1(C, 3 * C, self.norm.num_groups):
+            # the GroupNorm writes its result pre-split for the projection (no fp32 copy, no split per 64-channel output
+            # block): lc_conv1x1_f16x2_ps_fwd with its 16-byte store form -- 9.6 + 54 -> ~37 us at 512 -> 1536 @ 8 x 4 x 128
+            qkv = K.conv2d_ring(self.norm(x, split_for=self._pk_in), self._pk_in, w_in, self.attn.in_proj_bias)
         else:
             qkv = K.conv2d_ring(self.norm(x), self._pk_in, w_in, self.attn.in_proj_bias)
         t = qkv.view(B, 3 * C, H * W)
