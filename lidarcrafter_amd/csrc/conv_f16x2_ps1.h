@@ -274,12 +274,17 @@ __global__ __launch_bounds__((P1T<BPV, BNV, MIV>::NT), (BPV == 256 || BNV != 128
                     strip[((r & 3) + 8 * (r >> 2) + 4 * kh) * 36 + l31] = (acc[i][j][r] * out_unscale + bias_r[i][r]) * a.out_scale;
                 __builtin_amdgcn_wave_barrier();
                 const int cob = co0 + wco * WCO + i * 32, pb_ = p0 + wpx * 64 + j * 32 + 4 * (lane & 7);
+                // (all four reads first, into four register quads: no instruction may write the data registers of a
+                //  > 64-bit store directly behind it -- tests/test_isa_audit.py; the whole offset rides in the VGPR)
+                f32x4 v[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    v[it] = *reinterpret_cast<const f32x4*>(strip + (it * 8 + (lane >> 3)) * 36 + 4 * (lane & 7));
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + (lane >> 3);
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * 36 + 4 * (lane & 7));
                     const unsigned off = cob + row < a.Co && pb_ < a.P ? ((unsigned)(cob + row) * (unsigned)a.P + (unsigned)pb_) * 4u : 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lc_u32x4, v), rs_yb, off, 0, 16);   // sc1
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lc_u32x4, v[it]), rs_yb, off, 0, 16);   // sc1
                 }
             }
         return;
