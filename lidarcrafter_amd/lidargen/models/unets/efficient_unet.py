@@ -74,10 +74,11 @@ class SelfAttentionBlock(nn.Module):
         t = qkv.view(B, 3 * C, H * W)
         o = K.attention_cm(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], heads,
                            scale=1.0 / float(np.sqrt(C // heads)))
-        # out_proj + residual + 1/sqrt(2) in the conv epilogue
+        # out_proj + residual + 1/sqrt(2) in the conv epilogue (+ octet statistics of what it stores: the first GroupNorm of
+        # the next block then takes no statistics pass)
         return K.conv2d_ring(o.view(B, C, H, W), self._pk_out,
                              self.attn.out_proj.weight[:, :, None, None], self.attn.out_proj.bias,
-                             res=x, out=out, out_scale=self._scale_f)
+                             res=x, out=out, out_scale=self._scale_f, emit_stats=True)
 
 
 class ResidualBlock(nn.Module):
