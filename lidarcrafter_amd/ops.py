@@ -1187,6 +1187,8 @@ def conv_down2(x: torch.Tensor, packed: PackedConv, weight, bias, out: Optional[
 # of the reference stays (profiles/r06_fold_up.txt: 64 -> 64 @ 8 x 16 x 512 folded 93 us against 89).
 FOLD_UP = _os.environ.get("LC_FOLD_UP", "1") != "0"
 FOLD_UP_MIN_CI = int(_os.environ.get("LC_FOLD_UP_MIN_CI", "128"))
+# working set (nine planes + output) of one projection + combine pair, MB; a batch above it runs in slabs of samples; 0: one slab
+FOLD_UP_SLAB_MB = int(_os.environ.get("LC_FOLD_UP_SLAB_MB", "224"))
 
 
 def can_fold_up(Ci: int, Co: int, H: int, W: int) -> bool:
@@ -1242,22 +1244,32 @@ def conv_up2(xs, packed9: PackedConv, weight9: torch.Tensor, bias: Optional[torc
     wh, wl = packed9.get_f16x2(weight9)
     if packed9.ks != 1 or packed9.Ci != Ci:
         raise ValueError("conv_up2: packed9 does not hold weight9")
-    p9 = torch.empty((B, 9 * Co, H, W), device=dev, dtype=_F32)
-    # (algorithmic work = the reference's 3x3 conv at the HIGH resolution, which this launch replaces; it executes a quarter)
-    with _Timed("conv3x3", 2.0 * B * 4 * H * W * Co * Ci * 9, executed=2.0 * B * H * W * 9 * Co * Ci,
-                rd=4.0 * (B * Ci * H * W + Co * Ci * 9), wr=4.0 * B * 9 * Co * H * W):
-        check(_conv_lib().lc_conv1x1_f16x2_ps_fwd(xs.buf.data_ptr(), wh.data_ptr(), wl.data_ptr(), None, None, 0,
-                                                  p9.data_ptr(), 9 * Co * H * W, B, Ci, 9 * Co, H, W, 1.0,
-                                                  packed9.wmeta.data_ptr(), packed9.range_ptr(dev), _stream()),
-              "lc_conv1x1_f16x2_ps_fwd")
     sbuf, slots = None, 0
     if emit_stats and PRODUCER_GN_STATS:
         slots = int(lib().lc_up2_combine9_stats_slots(H, W))
         if slots > 0:
             sbuf = torch.empty((B, Co, slots, 4), device=dev, dtype=_F32)
-    with _Timed("resample", 4.0 * B * Co * H * W * 13.0):
-        check(lib().lc_up2_combine9_fwd(p9.data_ptr(), _bs4(p9, "p9"), _p(bias), out.data_ptr(), y_bs, B, Co, H, W,
-                                        _p(sbuf), _stream()), "lc_up2_combine9_fwd")
+    # Slabs of samples: the nine planes of a slab + its output should stay inside the 256 MB Infinity Cache between the two
+    # launches (the combine pass runs at ~6 TB/s on a 218 MB working set and at 3.4 TB/s on 436 MB, profiles/r06_fold_up.txt)
+    per_sample = 4.0 * (9 + 4) * Co * H * W
+    nb = B if FOLD_UP_SLAB_MB <= 0 else max(1, min(B, int(FOLD_UP_SLAB_MB * 2.0 ** 20 // per_sample)))
+    while B % nb:
+        nb -= 1
+    p9 = torch.empty((nb, 9 * Co, H, W), device=dev, dtype=_F32)
+    xs_bs = xs.buf.numel() // B * 2          # bytes per sample of the pre-split operand (fp16 elements)
+    st = _stream()
+    for b0 in range(0, B, nb):
+        # (algorithmic work = the reference's 3x3 conv at the HIGH resolution, which this launch replaces; it executes a quarter)
+        with _Timed("conv3x3", 2.0 * nb * 4 * H * W * Co * Ci * 9, executed=2.0 * nb * H * W * 9 * Co * Ci,
+                    rd=4.0 * (nb * Ci * H * W + Co * Ci * 9), wr=4.0 * nb * 9 * Co * H * W):
+            check(_conv_lib().lc_conv1x1_f16x2_ps_fwd(xs.buf.data_ptr() + b0 * xs_bs, wh.data_ptr(), wl.data_ptr(), None, None,
+                                                      0, p9.data_ptr(), 9 * Co * H * W, nb, Ci, 9 * Co, H, W, 1.0,
+                                                      packed9.wmeta.data_ptr(), packed9.range_ptr(dev), st),
+                  "lc_conv1x1_f16x2_ps_fwd")
+        with _Timed("resample", 4.0 * nb * Co * H * W * 13.0):
+            check(lib().lc_up2_combine9_fwd(p9.data_ptr(), 9 * Co * H * W, _p(bias), out.data_ptr() + 4 * b0 * y_bs, y_bs,
+                                            nb, Co, H, W, None if sbuf is None else sbuf.data_ptr() + 16 * b0 * Co * slots,
+                                            st), "lc_up2_combine9_fwd")
     if sbuf is not None:
         _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, 4 * H * W), 1))
     return out

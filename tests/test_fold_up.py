@@ -225,6 +225,26 @@ def test_fold_up_statistics_feed_groupnorm(dev, B, Ci, Co, H, W, G, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(4, 64, 4, 256), (6, 32, 2, 128), (8, 128, 16, 512)])
+def test_fold_up_in_slabs_of_samples_is_bit_equal(dev, B, C, H, W, monkeypatch):
+    """A batch whose nine planes would not stay inside the Infinity Cache runs as slabs of samples through the same two
+    kernels (ops.FOLD_UP_SLAB_MB): same bits, same statistics entries."""
+    from lidarcrafter_amd import ops as K
+
+    monkeypatch.setattr(K, "FOLD_UP_MIN_CI", 32)
+    conv = _layer(C, C, 120 + C, dev)
+    x = (seeded_randn(B, C, H, W, seed=700 + C) * 0.8 + 0.1).to(dev)
+    monkeypatch.setattr(K, "FOLD_UP_SLAB_MB", 0)
+    y0 = _fold(x, conv, emit_stats=True)
+    per_sample_mb = 4.0 * 13 * C * H * W / 2 ** 20
+    for slab_samples in (1, 2, 3):
+        monkeypatch.setattr(K, "FOLD_UP_SLAB_MB", max(1, int(per_sample_mb * slab_samples + 0.999)))
+        y1 = _fold(x, conv, emit_stats=True)
+        assert torch.equal(y0, y1), slab_samples
+        assert torch.equal(y0._lc_gnstats[(0, C)].buf, y1._lc_gnstats[(0, C)].buf), slab_samples
+
+
+@pytest.mark.gpu
 def test_fold_up_range_safety(dev, monkeypatch):
     """Operands the default pre-scale cannot hold (|x| ~ 3e4): the split pass publishes max |x * scale| into the layer's
     range record, the poll re-derives the scale, and the recomputed result is fp32-class."""
