@@ -324,15 +324,25 @@ static bool p1_small_tile(int B, long long P, int Co) {
     const long long blocks256 = (long long)B * ((P + 255) / 256) * ((Co + 127) / 128);
     return blocks256 <= 256;      // (384 blocks -- 256 -> 768 @ 8 x 256 at batch 8 -- measure 42 against 46.5 us inside a step)
 }
+// ... and for the plain kernel when the launch is output-heavy (Co >= 4 Ci: the nine-plane projections of the up-path fold --
+// 16-byte stores of one block under the other block's K loop: 80.4 -> 72.7 us at 256 -> 2304 @ 8 x 8 x 256, 109.6 -> 105.0 at
+// 128 -> 1152 @ 8 x 16 x 512, 43.7 -> 39.7 at 64 -> 576)
+static bool p1_small_tile_plain(int B, long long P, int Ci, int Co) {
+    static const int env = [] { const char* e = getenv("LC_P1_BP"); return e ? atoi(e) : 0; }();
+    if (env == 128) return true;
+    if (env == 256) return false;
+    return Co >= 4 * Ci || p1_small_tile(B, P, Co);
+}
 
-// 288-channel blocks when the output channels divide into them (9 Co' of the up-path fold) and the grid is at most two rounds
-// of the chip (256 / 512 blocks where the 128-channel forms run 1.125 / 2.25 rounds: 30.5 -> 22.8 us at 256 -> 2304 @ 8 x 4 x 128,
-// 75.4 -> 67.7 at 512 -> 4608; on longer grids the 128-channel forms are ahead: 78.9 against 84.9 us at 256 -> 2304 @ 8 x 8 x 256);
-// LC_P1_BN=128 / 288 forces one
+// 288-channel blocks when the output channels divide into them (9 Co' of the up-path fold) and the grid is ONE round of the
+// chip (256 blocks where the 128-channel forms run 1.125 rounds: 30.5 -> 22.8 us at 256 -> 2304 @ 8 x 4 x 128); on longer grids
+// the 128-channel x 128-pixel form (two blocks per CU: one block's epilogue under the other's K loop) is level or ahead:
+// 512 -> 4608 @ 8 x 4 x 128 68.9 (wide) / 68.7, 128 -> 1152 @ 8 x 8 x 256 31.1 / 28.9, 256 -> 2304 @ 8 x 8 x 256 84.9 / 72.7
+// (profiles/r06_fold_up.txt section 6); LC_P1_BN=128 / 288 forces one
 static bool p1_wide_tile(int B, long long P, int Co) {
     static const int env = [] { const char* e = getenv("LC_P1_BN"); return e ? atoi(e) : 0; }();
     if (Co % 288 || env == 128) return false;
-    return env == 288 || (long long)B * ((P + 127) / 128) * (Co / 288) <= 512;
+    return env == 288 || (long long)B * ((P + 127) / 128) * (Co / 288) <= 256;
 }
 
 // LC_P1_ST=0: the dword form of the plain epilogue everywhere (developer A/B)
@@ -366,7 +376,7 @@ extern "C" int lc_conv1x1_f16x2_ps_fwd(const void* x_split, const void* wp_hi, c
         hipLaunchKernelGGL((conv1x1_ps_kernel<false, 128, 288, 3>), grid, dim3(PW::NT), 0, lc_s(s), a);
         return lc_launch_status();
     }
-    if (p1_small_tile(B, P, Co)) {
+    if (p1_small_tile_plain(B, P, Ci, Co)) {
         dim3 grid((unsigned)(B * ((P + 127) / 128)), (unsigned)((Co + P1::BN - 1) / P1::BN));
         hipLaunchKernelGGL((conv1x1_ps_kernel<false, 128>), grid, dim3(P1T<128>::NT), 0, lc_s(s), a);
         return lc_launch_status();
