@@ -289,3 +289,35 @@ def test_models_take_the_folded_route(dev, monkeypatch):
         y0 = m(x, lam).clone()
     assert len(calls) == n
     assert rel_l2(y1, y0) < 5e-6, rel_l2(y1, y0)
+
+
+@pytest.mark.gpu
+def test_layout_model_takes_the_folded_route(dev, monkeypatch):
+    """LayoutUnetV1 (box-layout-v6 at 32 x 1024): its three up-sampling ResBlocks go through ops.conv_up2 (the GroupNorm apply
+    pass writes the low-resolution operand pre-split, x is up-sampled beside it), and the forward agrees with the reference's
+    order of operations (LC_FOLD_UP=0) to fp32-class accuracy.  The reference-pinned goldens of this model
+    (test_cond_full_golden, test_c3_b8_golden) run through the fold by default."""
+    from lidarcrafter_amd import ops as K
+    from lidarcrafter_amd.testing import synth_layout_batch
+    from lidargen.utils import inference
+    from lidargen.utils.configs import __all__ as C
+
+    ddpm, model, _ = inference.load_model_duffusion_training(C["nuscenes-box-layout-v6"]())
+    seeded_fill(model, salt=200), seeded_fill(ddpm.condition_model, salt=201)
+    ddpm = ddpm.eval().to(dev)
+    batch = {k: v.to(dev) for k, v in synth_layout_batch(2, 32, 1024, seed=53).items()}
+    calls = []
+    orig = K.conv_up2
+    monkeypatch.setattr(K, "conv_up2", lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
+    x = seeded_randn(2, 2, 32, 1024, seed=54).to(dev)
+    with torch.no_grad():
+        cond = ddpm.condition_model(batch)
+        tc = {"time_condition": torch.tensor([-0.5, 1.0], device=dev), "other_condition": cond}
+        y1 = ddpm.model(x, tc).clone()
+    assert sorted(s[1] for s in calls) == [128, 256, 512], calls
+    n = len(calls)
+    monkeypatch.setattr(K, "FOLD_UP", False)
+    with torch.no_grad():
+        y0 = ddpm.model(x, tc).clone()
+    assert len(calls) == n
+    assert rel_l2(y1, y0) < 5e-6, rel_l2(y1, y0)
