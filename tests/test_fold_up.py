@@ -79,6 +79,49 @@ def test_folded_algebra_and_oracle_vs_reference_golden(golden, tag):
         assert rel_l2(got[:, :, r], ora[:, :, r].double()) < 1e-6, r
 
 
+def test_combine_kernel_coefficients_restated():
+    """The coefficient table of up2_combine9_kernel (csrc/upfold.hip: hz0 / hz1 per low-resolution row, the three-row window
+    with its two dropped border terms) restated lane by lane in float64, against the plane-wise model above."""
+    torch.manual_seed(0)
+    B, Ci, Co, H, W = 1, 4, 3, 5, 8
+    x = torch.randn(B, Ci, H, W, dtype=torch.float64)
+    w = torch.randn(Co, Ci, 3, 3, dtype=torch.float64)
+    b = torch.randn(Co, dtype=torch.float64)
+    want = folded_model(x, w, b)
+    P = torch.einsum("toc,bchw->btohw", w.permute(2, 3, 0, 1).reshape(9, Co, Ci), x)[0]          # [9, Co, H, W]
+
+    def hz0(p0m, p0, p1m, p1, p2, p2p):      # output column 2j
+        return .75 * p0m + .25 * p0 + .25 * p1m + .75 * p1 + .75 * p2 + .25 * p2p
+
+    def hz1(p0m, p0, p1, p1p, p2, p2p):      # output column 2j + 1
+        return .25 * p0m + .75 * p0 + .75 * p1 + .25 * p1p + .25 * p2 + .75 * p2p
+
+    out = torch.zeros(Co, 2 * H, 2 * W, dtype=torch.float64)
+    j0 = torch.arange(0, W, 2)                                    # a lane owns columns j0, j0 + 1
+    jm, jp = (j0 - 1) % W, (j0 + 2) % W
+
+    def horiz(i):                                                 # -> [3 ky][4 columns][Co, lanes]
+        if i < 0 or i >= H:
+            return [[torch.zeros(Co, len(j0), dtype=torch.float64)] * 4 for _ in range(3)]
+        res = []
+        for ky in range(3):
+            t0, t1, t2 = 3 * ky, 3 * ky + 1, 3 * ky + 2
+            L, A, Bv, R = (lambda t: P[t, :, i, jm]), (lambda t: P[t, :, i, j0]), (lambda t: P[t, :, i, j0 + 1]), (lambda t: P[t, :, i, jp])
+            res.append([hz0(L(t0), A(t0), L(t1), A(t1), A(t2), Bv(t2)), hz1(L(t0), A(t0), A(t1), Bv(t1), A(t2), Bv(t2)),
+                        hz0(A(t0), Bv(t0), A(t1), Bv(t1), Bv(t2), R(t2)), hz1(A(t0), Bv(t0), Bv(t1), R(t1), Bv(t2), R(t2))])
+        return res
+
+    for i in range(H):
+        Hm, H0, Hp = horiz(i - 1), horiz(i), horiz(i + 1)
+        ft, fb = float(i > 0), float(i + 1 < H)
+        for c in range(4):
+            top = ft * (.25 * H0[0][c] + .75 * Hm[0][c]) + .25 * Hm[1][c] + .75 * H0[1][c] + .75 * H0[2][c] + .25 * Hp[2][c]
+            bot = fb * (.75 * Hp[2][c] + .25 * H0[2][c]) + .25 * Hm[0][c] + .75 * H0[0][c] + .75 * H0[1][c] + .25 * Hp[1][c]
+            out[:, 2 * i, 2 * j0 + c] = top + b[:, None]
+            out[:, 2 * i + 1, 2 * j0 + c] = bot + b[:, None]
+    assert float((out - want[0]).abs().max()) < 1e-12
+
+
 def test_up9_weight_layout_and_eligibility():
     from lidarcrafter_amd import ops as K
 
