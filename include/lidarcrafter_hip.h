@@ -326,6 +326,10 @@ int lc_split_act_fwd(const float* x, int64_t x_bs, void* y_split, int B, int C, 
 int64_t lc_up2_combine9_stats_slots(int H, int W);
 int lc_up2_combine9_fwd(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs, int B, int Co, int H,
                         int W, float* ostats, lc_stream_t s);
+/* ... the same, and y2 [B][Co][2H][2W] = Resample(up=2)(x) of a second low-resolution tensor x [B][Co][H][W] in the same launch
+ * (the skip path of LayoutUnetV1's up-sampling ResBlock, layout_unet_v1.py:232; bit-identical to lc_resample2x_fwd). */
+int lc_up2_combine9_xup_fwd(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs, const float* x,
+                            int64_t x_bs, float* y2, int64_t y2_bs, int B, int Co, int H, int W, float* ostats, lc_stream_t s);
 
 /* ---------------------------------------------------------------------------------------------
  * Small dense layer  y[m, n] = sum_k act(x[m,k]) * w[n,k] + b[n]   (w in nn.Linear layout).

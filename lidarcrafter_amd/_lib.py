@@ -103,6 +103,7 @@ SIGNATURES = {
     "lc_split_act_fwd": (i32, [vp, i64, vp, i32, i32, i32, i32, vp, vp]),
     "lc_up2_combine9_stats_slots": (i64, [i32, i32]),
     "lc_up2_combine9_fwd": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
+    "lc_up2_combine9_xup_fwd": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]),
     "lc_attention_units_elems": (i64, [i32, i32, i32, i32]),
     "lc_attention_pack_units": (i32, [_op, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lc_attention_units_fwd": (i32, [_op, _op, vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),

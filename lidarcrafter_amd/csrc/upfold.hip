@@ -89,11 +89,27 @@ __device__ __forceinline__ float hz1(float p0m, float p0, float p1, float p1p, f
     return fmaf(0.75f, p2p, s);
 }
 
-template <bool STATS>
+// XUP: the same launch also writes Resample(up=2)(x) of a second low-resolution tensor x [B][Co][H][W] into y2 -- the skip path
+// of LayoutUnetV1's up-sampling ResBlock (layout_unet_v1.py:232: x = self.op(x)), which shares the (sample, channel, segment,
+// row) walk of this kernel: one launch and one pass over the row window instead of a second kernel.  Arithmetic and order of
+// resample.hip's up2_kernel (no contraction): bit-identical to lc_resample2x_fwd.
+struct XupArgs { const float* x; long long x_bs; float* y2; long long y2_bs; };
+#pragma clang fp contract(off)
+__device__ __forceinline__ void xup_row(float xm, float xa, float xb, float xp, float (&o)[4]) {
+    o[0] = 0.25f * xm + 0.75f * xa;      // ev(j0)
+    o[1] = 0.75f * xa + 0.25f * xb;      // od(j0)
+    o[2] = 0.25f * xa + 0.75f * xb;      // ev(j0 + 1)
+    o[3] = 0.75f * xb + 0.25f * xp;      // od(j0 + 1)
+}
+__device__ __forceinline__ float xup_top(float m, float c) { return 0.25f * m + 0.75f * c; }
+__device__ __forceinline__ float xup_bot(float c, float p) { return 0.75f * c + 0.25f * p; }
+#pragma clang fp contract(fast)
+
+template <bool STATS, bool XUP>
 __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restrict__ p9, long long p_bs,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           long long y_bs, int Co, int H, int W,
-                                                          f32x4* __restrict__ ostats) {
+                                                          f32x4* __restrict__ ostats, XupArgs xa) {
     const int segs = W >> 7;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= Co * segs) return;                                   // (wave-uniform)
@@ -109,6 +125,8 @@ __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restri
     const unsigned col_off = (unsigned)(2 * j0) * 4u, row_bytes = (unsigned)(2 * W) * 4u;
 
     float L[9], A[9], Bv[9], R[9];
+    float xl = 0.f, xc0 = 0.f, xc1 = 0.f, xr = 0.f;                  // XUP: the raw row of x
+    const float* xb_ = XUP ? xa.x + b * xa.x_bs + (long long)co * HW : nullptr;
     auto load_row = [&](int i) {
         const float* row = pb + (long long)i * W;
 #pragma unroll
@@ -117,7 +135,19 @@ __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restri
             const float2 v = *reinterpret_cast<const float2*>(q + j0);
             L[t] = q[jm]; A[t] = v.x; Bv[t] = v.y; R[t] = q[jp];
         }
+        if (XUP) {
+            const float* q = xb_ + (long long)i * W;
+            const float2 v = *reinterpret_cast<const float2*>(q + j0);
+            xl = q[jm]; xc0 = v.x; xc1 = v.y; xr = q[jp];
+        }
     };
+    float Xm[4] = {0.f, 0.f, 0.f, 0.f}, X0[4] = {0.f, 0.f, 0.f, 0.f}, Xp[4] = {0.f, 0.f, 0.f, 0.f};
+    auto xrow = [&](float (&o)[4], bool inside) {                    // rows outside the image are zeros (not 0 * x: NaN-safe)
+        xup_row(xl, xc0, xc1, xr, o);
+        if (!inside) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+    };
+    float* y2c = XUP ? xa.y2 + b * xa.y2_bs + (long long)co * 4 * HW : nullptr;
+    const __amdgpu_buffer_rsrc_t rs_y2 = lc_wt_buf(y2c);
     auto horiz = [&](float (&Hh)[3][4], float f) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -135,8 +165,10 @@ __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restri
         for (int c = 0; c < 4; ++c) Hm[ky][c] = 0.0f;
     load_row(0);
     horiz(H0, 1.0f);
+    if (XUP) xrow(X0, true);
     load_row(H > 1 ? 1 : 0);
     horiz(Hp, H > 1 ? 1.0f : 0.0f);
+    if (XUP) xrow(Xp, H > 1);
     for (int i = 0; i < H; ++i) {
         // rows past the image are read as the last row and multiplied by 0 (no branch around the loads)
         load_row(i + 2 < H ? i + 2 : H - 1);
@@ -162,6 +194,13 @@ __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restri
         const unsigned off = (unsigned)(2 * i) * row_bytes + col_off;
         lc_st4(rs_y, off, top);
         lc_st4(rs_y, off + row_bytes, bot);
+        if (XUP) {
+            f32x4 xt, xb2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { xt[c] = xup_top(Xm[c], X0[c]); xb2[c] = xup_bot(X0[c], Xp[c]); }
+            lc_st4(rs_y2, off, xt);
+            lc_st4(rs_y2, off + row_bytes, xb2);
+        }
         if (STATS) {
             const float piv = __builtin_amdgcn_readfirstlane(top[0]);
             float s_ = 0.0f, q_ = 0.0f;
@@ -179,6 +218,12 @@ __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restri
         }
         float Hn[3][4];
         horiz(Hn, i + 2 < H ? 1.0f : 0.0f);
+        if (XUP) {
+            float Xn[4];
+            xrow(Xn, i + 2 < H);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { Xm[c] = X0[c]; X0[c] = Xp[c]; Xp[c] = Xn[c]; }
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -213,22 +258,39 @@ extern "C" int64_t lc_up2_combine9_stats_slots(int H, int W) {
 // low-resolution operand by W[:, :, ky, kx]); y: [B][Co][2H][2W] = conv3x3_ring(Resample(up=2)(a)) + bias.
 // ostats: NULL or [B][Co][slots][4] (lc_oct_stats with unit = 1, slots = lc_up2_combine9_stats_slots(H, W)).
 // W % 128 == 0 (LC_EUNSUP otherwise); p9 8-byte, y 16-byte aligned with even / 4-multiple batch strides.
-extern "C" int lc_up2_combine9_fwd(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs, int B,
-                                   int Co, int H, int W, float* ostats, lc_stream_t s) {
+static int up2_combine9(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs, int B, int Co, int H, int W,
+                        float* ostats, const float* x, int64_t x_bs, float* y2, int64_t y2_bs, lc_stream_t s) {
     if (!p9 || !y || B <= 0 || Co <= 0 || H <= 0 || W <= 0) return LC_EINVAL;
     if (W % 128 || (p_bs & 1) || (y_bs & 3) || (reinterpret_cast<uintptr_t>(p9) & 7) ||
         (reinterpret_cast<uintptr_t>(y) & 15))
         return LC_EUNSUP;
+    if (x && ((x_bs & 1) || (y2_bs & 3) || (reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(y2) & 15)))
+        return LC_EUNSUP;
     if (16ll * H * W >= (1ll << 32)) return LC_EUNSUP;              // 32-bit byte offsets inside one output plane
     const long long items = (long long)Co * (W / 128);
     const dim3 grid((unsigned)((items + 3) / 4), B);
-    if (ostats)
-        hipLaunchKernelGGL(up2_combine9_kernel<true>, grid, dim3(256), 0, lc_s(s), p9, (long long)p_bs, bias, y,
-                           (long long)y_bs, Co, H, W, reinterpret_cast<f32x4*>(ostats));
-    else
-        hipLaunchKernelGGL(up2_combine9_kernel<false>, grid, dim3(256), 0, lc_s(s), p9, (long long)p_bs, bias, y,
-                           (long long)y_bs, Co, H, W, (f32x4*)nullptr);
+    const XupArgs xa{x, (long long)x_bs, y2, (long long)y2_bs};
+    f32x4* os = reinterpret_cast<f32x4*>(ostats);
+#define LC_UPC(ST, XU) hipLaunchKernelGGL((up2_combine9_kernel<ST, XU>), grid, dim3(256), 0, lc_s(s), p9, (long long)p_bs, \
+                                          bias, y, (long long)y_bs, Co, H, W, os, xa)
+    if (ostats) { if (x) LC_UPC(true, true); else LC_UPC(true, false); }
+    else { if (x) LC_UPC(false, true); else LC_UPC(false, false); }
+#undef LC_UPC
     return lc_launch_status();
 }
 
-LC_TOUCH_TU(upfold, up2_combine9_kernel<true>)
+extern "C" int lc_up2_combine9_fwd(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs, int B,
+                                   int Co, int H, int W, float* ostats, lc_stream_t s) {
+    return up2_combine9(p9, p_bs, bias, y, y_bs, B, Co, H, W, ostats, nullptr, 0, nullptr, 0, s);
+}
+
+// ... and y2 = Resample(up=2)(x) for x [B][Co][H][W] in the same launch (bit-identical to lc_resample2x_fwd): the skip path of
+// LayoutUnetV1's up-sampling ResBlock.  x 8-byte, y2 16-byte aligned, even / 4-multiple batch strides (LC_EUNSUP otherwise).
+extern "C" int lc_up2_combine9_xup_fwd(const float* p9, int64_t p_bs, const float* bias, float* y, int64_t y_bs,
+                                       const float* x, int64_t x_bs, float* y2, int64_t y2_bs, int B, int Co, int H, int W,
+                                       float* ostats, lc_stream_t s) {
+    if (!x || !y2) return LC_EINVAL;
+    return up2_combine9(p9, p_bs, bias, y, y_bs, B, Co, H, W, ostats, x, x_bs, y2, y2_bs, s);
+}
+
+LC_TOUCH_TU(upfold, up2_combine9_kernel<true, false>)

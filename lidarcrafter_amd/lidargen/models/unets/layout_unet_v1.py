@@ -133,8 +133,13 @@ class ResBlock(TimestepBlock):
             if a is not None:
                 # conv3x3(up(a)) computed at the LOW resolution: one 1x1 projection to the nine tap planes (a quarter of the
                 # multiply-adds) + the combine pass (ops.conv_up2, csrc/upfold.hip); it leaves per-channel statistics entries
-                h = K.conv_up2(a, self._packed_up9, self._up9_weight(), self.in_layers[2].bias, emit_stats=True)
-                x = self.op(x)
+                # (x's own up-sampling rides in the combine launch where the two tensors have the same channels)
+                if K.FOLD_UP_X and x.shape[1] == self.out_channels:
+                    h, x = K.conv_up2(a, self._packed_up9, self._up9_weight(), self.in_layers[2].bias, emit_stats=True,
+                                      up_also=x)
+                else:
+                    h = K.conv_up2(a, self._packed_up9, self._up9_weight(), self.in_layers[2].bias, emit_stats=True)
+                    x = self.op(x)
                 a2 = self.out_layers[0](h, scale, shift, act_silu=True, split_for=self.out_layers[3]._packed)
                 sk = x if isinstance(self.skip_connection, nn.Identity) else self.skip_connection(x, out=h)
                 return self.out_layers[3](a2, res=sk, out=out, emit_stats=su)

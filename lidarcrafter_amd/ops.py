@@ -1187,6 +1187,8 @@ def conv_down2(x: torch.Tensor, packed: PackedConv, weight, bias, out: Optional[
 # of the reference stays (profiles/r06_fold_up.txt: 64 -> 64 @ 8 x 16 x 512 folded 93 us against 89).
 FOLD_UP = _os.environ.get("LC_FOLD_UP", "1") != "0"
 FOLD_UP_MIN_CI = int(_os.environ.get("LC_FOLD_UP_MIN_CI", "128"))
+# the skip path's Resample(up=2)(x) of an up-sampling ResBlock in the combine launch (lc_up2_combine9_xup_fwd); "0": its own launch
+FOLD_UP_X = _os.environ.get("LC_FOLD_UP_X", "1") != "0"
 # working set (nine planes + output) of one projection + combine pair, MB; a batch above it runs in slabs of samples; 0: one slab
 FOLD_UP_SLAB_MB = int(_os.environ.get("LC_FOLD_UP_SLAB_MB", "224"))
 
@@ -1219,11 +1221,14 @@ def split_act(x: torch.Tensor, packed: PackedConv) -> SplitAct:
 
 
 def conv_up2(xs, packed9: PackedConv, weight9: torch.Tensor, bias: Optional[torch.Tensor] = None,
-             out: Optional[torch.Tensor] = None, emit_stats=False) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, emit_stats=False, up_also: Optional[torch.Tensor] = None):
     """y = Conv2d_ring3x3(Resample(up=2)(a)) + bias of the reference for a [B, Ci, H, W] -> [B, Co, 2H, 2W], computed at the
     LOW resolution.  xs: `a` pre-split for `packed9` (a SplitAct from `groupnorm(..., split_for=packed9)` / `split_act`),
     weight9 = `up9_weight(conv.weight)` (the caller caches it per weight version), packed9 its PackedConv.
-    emit_stats: per-channel GroupNorm statistics entries of the result (any consumer folds them)."""
+    emit_stats: per-channel GroupNorm statistics entries of the result (any consumer folds them).
+    up_also: a second low-resolution tensor [B, Co, H, W] whose plain Resample(up=2) is written by the same combine launch
+    (the skip path of LayoutUnetV1's up-sampling ResBlock; bit-identical to `resample2x(up_also, up=True)`): the call then
+    returns (y, resample2x(up_also))."""
     if not isinstance(xs, SplitAct) or xs.packed is not packed9:
         raise ValueError("conv_up2: needs the operand pre-split for this layer (groupnorm(split_for=packed9) / split_act)")
     B, Ci, H, W = xs.shape
@@ -1241,6 +1246,17 @@ def conv_up2(xs, packed9: PackedConv, weight9: torch.Tensor, bias: Optional[torc
     if bias is not None:
         _req(bias, "bias")
     _drop_stats(out)
+    x2, y2, x2_bs, y2_bs = None, None, 0, 0
+    if up_also is not None:
+        x2 = up_also
+        x2_bs = _bs4(x2, "up_also")
+        if tuple(x2.shape) != (B, Co, H, W):
+            raise ValueError(f"conv_up2: up_also must be {(B, Co, H, W)}, got {tuple(x2.shape)}")
+        if x2.data_ptr() % 8 or x2_bs % 2:
+            x2 = x2.contiguous()
+            x2_bs = Co * H * W
+        y2 = torch.empty((B, Co, 2 * H, 2 * W), device=dev, dtype=_F32)
+        y2_bs = Co * 4 * H * W
     wh, wl = packed9.get_f16x2(weight9)
     if packed9.ks != 1 or packed9.Ci != Ci:
         raise ValueError("conv_up2: packed9 does not hold weight9")
@@ -1266,13 +1282,19 @@ def conv_up2(xs, packed9: PackedConv, weight9: torch.Tensor, bias: Optional[torc
                                                       0, p9.data_ptr(), 9 * Co * H * W, nb, Ci, 9 * Co, H, W, 1.0,
                                                       packed9.wmeta.data_ptr(), packed9.range_ptr(dev), st),
                   "lc_conv1x1_f16x2_ps_fwd")
-        with _Timed("resample", 4.0 * nb * Co * H * W * 13.0):
-            check(lib().lc_up2_combine9_fwd(p9.data_ptr(), 9 * Co * H * W, _p(bias), out.data_ptr() + 4 * b0 * y_bs, y_bs,
-                                            nb, Co, H, W, None if sbuf is None else sbuf.data_ptr() + 16 * b0 * Co * slots,
-                                            st), "lc_up2_combine9_fwd")
+        sp = None if sbuf is None else sbuf.data_ptr() + 16 * b0 * Co * slots
+        with _Timed("resample", 4.0 * nb * Co * H * W * (13.0 if x2 is None else 18.0)):
+            if x2 is None:
+                check(lib().lc_up2_combine9_fwd(p9.data_ptr(), 9 * Co * H * W, _p(bias), out.data_ptr() + 4 * b0 * y_bs, y_bs,
+                                                nb, Co, H, W, sp, st), "lc_up2_combine9_fwd")
+            else:
+                check(lib().lc_up2_combine9_xup_fwd(p9.data_ptr(), 9 * Co * H * W, _p(bias), out.data_ptr() + 4 * b0 * y_bs,
+                                                    y_bs, x2.data_ptr() + 4 * b0 * x2_bs, x2_bs,
+                                                    y2.data_ptr() + 4 * b0 * y2_bs, y2_bs, nb, Co, H, W, sp, st),
+                      "lc_up2_combine9_xup_fwd")
     if sbuf is not None:
         _attach_stats(out, _OctStatsHandle(sbuf, Co, slots, (B, 4 * H * W), 1))
-    return out
+    return out if up_also is None else (out, y2)
 
 
 # Split-K (pre-split conv): when a 3x3 conv has fewer than SPLITK_MAX_BLOCKS output tiles (batch

@@ -364,3 +364,28 @@ def test_layout_model_takes_the_folded_route(dev, monkeypatch):
         y0 = ddpm.model(x, tc).clone()
     assert len(calls) == n
     assert rel_l2(y1, y0) < 5e-6, rel_l2(y1, y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 4, 128), (3, 64, 1, 256), (8, 128, 16, 512), (2, 32, 5, 384)])
+def test_fold_up_with_the_skip_paths_upsampling_in_the_same_launch(dev, B, C, H, W, monkeypatch):
+    """lc_up2_combine9_xup_fwd: y as without it (same bits, same entries), and the second output bit-identical to
+    lc_resample2x_fwd of the second tensor -- in one slab and in slabs of samples."""
+    from lidarcrafter_amd import ops as K
+
+    monkeypatch.setattr(K, "FOLD_UP_MIN_CI", 32)
+    conv = _layer(C, C, 130 + C, dev)
+    a = (seeded_randn(B, C, H, W, seed=800 + C) * 0.7).to(dev)
+    wide = torch.empty((B, C + 8, H, W), device=dev)
+    x = wide[:, 8:]                                   # batch-strided second tensor
+    x.copy_((seeded_randn(B, C, H, W, seed=900 + C) * 1.5 + 0.3).to(dev))
+    pk = K.PackedConv("test.xup")
+    w9 = K.up9_weight(conv.weight)
+    y0 = K.conv_up2(K.split_act(a, pk), pk, w9, conv.bias, emit_stats=True)
+    want = K.resample2x(x, up=True)
+    per_sample_mb = 4.0 * 13 * C * H * W / 2 ** 20
+    for slab in (0, max(1, int(per_sample_mb + 0.999))):
+        monkeypatch.setattr(K, "FOLD_UP_SLAB_MB", slab)
+        y1, x1 = K.conv_up2(K.split_act(a, pk), pk, w9, conv.bias, emit_stats=True, up_also=x)
+        assert torch.equal(y0, y1) and torch.equal(y0._lc_gnstats[(0, C)].buf, y1._lc_gnstats[(0, C)].buf), slab
+        assert torch.equal(x1, want), (slab, float((x1 - want).abs().max()))
