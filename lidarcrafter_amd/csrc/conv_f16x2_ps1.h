@@ -84,12 +84,18 @@ __global__ __launch_bounds__((P1T<BPV, BNV, MIV>::NT), (BPV == 256 || BNV != 128
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave / WPX, wpx = wave % WPX;
     const int tiles_p = (a.P + BP - 1) / BP;
-    const int b = blockIdx.x / tiles_p, p0 = (blockIdx.x - b * tiles_p) * BP;
+    const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / tiles_p)), p0 = (blockIdx.x - b * tiles_p) * BP;
     const int co0 = blockIdx.y * BN;
 
     const unsigned xbytes = 2u * (unsigned)a.C8 * (unsigned)a.P * 16u;
+    // (the sample's base address through readfirstlane: the 64-bit product runs on the vector unit, and a descriptor in VGPRs
+    //  makes hipcc wrap every x DMA of the K loop in a waterfall loop -- 4-5 per chunk and wave; without them the nine-plane
+    //  projections run 3-7 % faster: 67.6 -> 63.4 us at 512 -> 4608, 71.9 -> 66.6 at 256 -> 2304 @ 8 x 8 x 256, profiles/r06_fold_up.txt)
+    const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.xsp + (long long)b * a.xsp_bs);
+    const unsigned long long xaddr_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xaddr >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)xaddr);
     __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.xsp + (long long)b * a.xsp_bs), 0, xbytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(xaddr_u), 0, xbytes, 0x00020000);
     const unsigned wplane = (unsigned)a.Cib * (unsigned)a.Cop;                 // units per weight plane (one tap)
     __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, 2u * wplane * 16u, 0x00020000);
 
@@ -263,7 +269,10 @@ __global__ __launch_bounds__((P1T<BPV, BNV, MIV>::NT), (BPV == 256 || BNV != 128
         //  aligned; the wave writes its tile in the accumulator layout and reads it back as rows -- LDS operations of one
         //  wave execute in order, the wave barriers only keep the compiler from moving them across each other)
         float* strip = reinterpret_cast<float*>(lds) + wave * (32 * 36);
-        const __amdgpu_buffer_rsrc_t rs_yb = __builtin_amdgcn_make_buffer_rsrc(yb, 0, 0x7FFFFFFFu, 0x00020000);
+        const unsigned long long ya = reinterpret_cast<unsigned long long>(yb);            // (uniform: keeps the descriptor in SGPRs)
+        const unsigned long long ya_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ya >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)ya);
+        const __amdgpu_buffer_rsrc_t rs_yb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ya_u), 0, 0x7FFFFFFFu, 0x00020000);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
