@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void up2_combine9_kernel(const float* __restri
                                                           long long y_bs, int Co, int H, int W,
                                                           f32x4* __restrict__ ostats, XupArgs xa) {
     const int segs = W >> 7;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (readfirstlane: the wave index is uniform, but only this tells hipcc -- otherwise channel / segment live in VGPRs, the output
+    //  descriptors with them, and every 16-byte store sits in a waterfall loop)
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= Co * segs) return;                                   // (wave-uniform)
     const int lane = threadIdx.x & 63, b = blockIdx.y;
     const int co = item / segs, sg = item - co * segs;

@@ -118,3 +118,23 @@ def test_tall_kernel_chunk_barrier_waits_cover_the_weight_dma(kernels):
             if not any(x.startswith(("s_cbranch", "s_branch")) for x in ins[i:b]):
                 steady += 1
         assert steady >= nch, (name[:70], steady)        # every chunk of the K loop was seen
+
+
+def test_no_waterfall_loops_in_the_streaming_and_projection_kernels(kernels):
+    """A buffer descriptor (or an LDS-DMA destination) that hipcc cannot prove wave-uniform is put through a waterfall loop:
+    v_readfirstlane x 4, v_cmp_eq_u64 x 2, s_and_saveexec, the memory operation, s_xor exec, s_cbranch_execnz -- per operation.
+    Round 6 found them around every x DMA of the pre-split 1x1 kernel's K loop (the sample's base address was a 64-bit product
+    on the vector unit: projections 3-7 % slower) and around the 16-byte stores of the combine pass (profiles/r06_fold_up.txt
+    section 9).  The kernels below must have none."""
+    hot = ("conv1x1_ps_kernel", "up2_combine9_kernel", "conv_f16x2_ps_kernel", "conv_f16x2_tall_kernel", "conv_s2_shared_w_kernel",
+           "gn_apply_split_kernel", "split_plain_kernel", "attn_u_kernel", "fir_down2_prefilter_split_kernel")
+    seen, bad = 0, []
+    for name, ins in kernels.items():
+        if not any(h in name for h in hot):
+            continue
+        seen += 1
+        n = sum(1 for i, t in enumerate(ins) if t.startswith("v_cmp_eq_u64") and any(u.startswith("s_and_saveexec") for u in ins[i:i + 5]))
+        if n:
+            bad.append((name[:80], n))
+    assert seen >= 20, seen
+    assert not bad, bad[:6]
